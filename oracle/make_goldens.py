@@ -1,0 +1,290 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules.  TEST INFRASTRUCTURE ONLY.
+
+Runs in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    python -B oracle/make_goldens.py
+
+The reference has no tests or golden vectors of its own, so parity is pinned by
+importing its hot-path modules here (recipe: SURVEY.md §8c), driving them with the seeded
+state-dict / inputs of ``conceptattention_amd.weights`` and committing inputs' checksums and
+outputs as data.  Nothing from the reference's source is written to the fixtures.
+
+Fixtures
+  tiny_schnell.npz / tiny_dev.npz   full ModifiedFluxDiT forward, H=256 NH=2 depth 2/2, 16x16 patches
+  tiny_ablation.npz                 joint_attention_kwargs branches of the double block
+  block_full.npz                    ONE full-size double block (H=3072, L=4096, T=256, C=4)
+  single_full.npz                   ONE full-size single block
+  heatmap_kat.npz                   compute_heatmaps_from_vectors known answers (softmax branch)
+  sampler.npz                       get_schedule / prepare-patchify / unpack / denoise (tiny, 2 steps)
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+import numpy as np
+import torch
+
+
+def _import_reference():
+    """Model-level recipe (i) + pipeline-level stubs (ii) of SURVEY.md §8c."""
+    import transformers  # noqa: F401  (must be imported before the stubs below)
+    pkg = types.ModuleType("concept_attention")
+    pkg.__path__ = [REF + "/concept_attention"]
+    sys.modules["concept_attention"] = pkg
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    stub("entmax", entmax15=None, sparsemax=None)
+
+    class _WM:
+        def set_watermark(self, *a, **k):
+            pass
+
+        def encode(self, x, *a, **k):
+            return x
+    stub("imwatermark", WatermarkEncoder=_WM)
+    stub("fire", Fire=lambda *a, **k: None)
+    tv = stub("torchvision")
+    tv.transforms = stub("torchvision.transforms", Compose=None, ToTensor=None, Lambda=None)
+    tv.transforms.functional = stub("torchvision.transforms.functional")
+    from concept_attention.modified_flux_dit import ModifiedFluxDiT, FluxParams
+    from concept_attention.modified_double_stream_block import ModifiedDoubleStreamBlock
+    from concept_attention.modified_single_stream_block import ModifiedSingleStreamBlock
+    from concept_attention.concept_attention_pipeline import compute_heatmaps_from_vectors
+    from concept_attention.flux.src.flux import sampling
+    return dict(ModifiedFluxDiT=ModifiedFluxDiT, FluxParams=FluxParams,
+                ModifiedDoubleStreamBlock=ModifiedDoubleStreamBlock,
+                ModifiedSingleStreamBlock=ModifiedSingleStreamBlock,
+                compute_heatmaps_from_vectors=compute_heatmaps_from_vectors, sampling=sampling)
+
+
+def _checksum(t: torch.Tensor) -> np.ndarray:
+    t = t.double().flatten()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * torch.arange(t.numel()) % 7).sum().item()])
+
+
+def _ref_params(ref, p):
+    return ref["FluxParams"](in_channels=p.in_channels, vec_in_dim=p.vec_in_dim,
+                             context_in_dim=p.context_in_dim, hidden_size=p.hidden_size,
+                             mlp_ratio=p.mlp_ratio, num_heads=p.num_heads, depth=p.depth,
+                             depth_single_blocks=p.depth_single_blocks, axes_dim=list(p.axes_dim),
+                             theta=p.theta, qkv_bias=p.qkv_bias, guidance_embed=p.guidance_embed)
+
+
+def tiny_model(ref, out_dir, guidance_embed, name):
+    from conceptattention_amd.params import tiny_params
+    from conceptattention_amd.weights import synthetic_state_dict, synthetic_inputs
+    from oracle.flux_oracle import patchify
+    p = tiny_params(guidance_embed=guidance_embed)
+    sd = synthetic_state_dict(p, seed=1)
+    model = ref["ModifiedFluxDiT"](_ref_params(ref, p)).eval()
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    inp = synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=3, seed=2)
+    img = patchify(inp["latent"])
+    t = torch.tensor([0.75])
+    gvec = torch.tensor([3.5])
+    with torch.no_grad():
+        pred, d = model(img=img, img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
+                        concepts=inp["concepts"], concept_ids=inp["concept_ids"],
+                        concept_vec=inp["concept_vec"], y=inp["vec"], timesteps=t, guidance=gvec)
+        none_pred, d2 = model(img=img, img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
+                              concepts=inp["concepts"], concept_ids=inp["concept_ids"],
+                              concept_vec=inp["concept_vec"], y=inp["concept_vec"], timesteps=t,
+                              guidance=gvec, stop_after_multimodal_attentions=True)
+    assert none_pred is None
+    arrays = {"pred": pred.numpy(), "timestep": t.numpy(), "guidance": gvec.numpy(),
+              "in_checksum_img": _checksum(img), "in_checksum_txt": _checksum(inp["txt"]),
+              "w_checksum": _checksum(sd["double_blocks.1.img_mlp.2.weight"])}
+    for k, v in d.items():
+        arrays[k] = v.numpy()
+    for k, v in d2.items():
+        arrays["stop_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(out_dir, name), **arrays)
+    print(name, {k: v.shape for k, v in arrays.items()})
+
+
+def tiny_ablation(ref, out_dir):
+    from conceptattention_amd.params import tiny_params
+    from conceptattention_amd.weights import synthetic_state_dict, synthetic_inputs
+    from oracle.flux_oracle import patchify
+    p = tiny_params(depth=1, depth_single_blocks=0)
+    sd = synthetic_state_dict(p, seed=1)
+    model = ref["ModifiedFluxDiT"](_ref_params(ref, p)).eval()
+    model.load_state_dict(sd, strict=True)
+    inp = synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=3, seed=2)
+    img = patchify(inp["latent"])
+    arrays = {}
+    for cross in (True, False):
+        for self_ in (True, False):
+            with torch.no_grad():
+                _, d = model(img=img, img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
+                             concepts=inp["concepts"], concept_ids=inp["concept_ids"],
+                             concept_vec=inp["concept_vec"], y=inp["vec"], timesteps=torch.tensor([0.5]),
+                             stop_after_multimodal_attentions=True,
+                             joint_attention_kwargs={"concept_cross_attention": cross,
+                                                     "concept_self_attention": self_})
+            tag = f"cross{int(cross)}_self{int(self_)}_"
+            arrays[tag + "output_space_concept_vectors"] = d["output_space_concept_vectors"].numpy()
+            arrays[tag + "cross_attention_concept_vectors"] = d["cross_attention_concept_vectors"].numpy()
+    np.savez_compressed(os.path.join(out_dir, "tiny_ablation.npz"), **arrays)
+    print("tiny_ablation", list(arrays))
+
+
+def full_blocks(ref, out_dir):
+    """One full-size double block and one full-size single block (fp32, seeded bf16-representable
+    weights and inputs so the HIP bf16 path sees the *same* numbers)."""
+    from conceptattention_amd.params import FluxParams
+    from conceptattention_amd.weights import synthetic_state_dict
+    from oracle.flux_oracle import rope_cos_sin, make_img_ids
+    from oracle.full_block_case import full_block_inputs
+    p = FluxParams()
+    H, NH = p.hidden_size, p.num_heads
+    case = full_block_inputs(p)
+    # ---------------- double block
+    sd = synthetic_state_dict(p, seed=0, prefix="double_blocks.0.")
+    sd = {k[len("double_blocks.0."):]: v.bfloat16().float() for k, v in sd.items()}
+    blk = ref["ModifiedDoubleStreamBlock"](H, NH, mlp_ratio=p.mlp_ratio, qkv_bias=True).eval()
+    blk.load_state_dict(sd, strict=True)
+    from concept_attention.flux.src.flux.modules.layers import EmbedND
+    emb = EmbedND(dim=128, theta=p.theta, axes_dim=list(p.axes_dim))
+    pe = emb(torch.cat((case["txt_ids"], case["img_ids"]), 1))
+    cpe = emb(torch.cat((case["concept_ids"], case["img_ids"]), 1))
+    with torch.no_grad():
+        img, txt, con, d = blk(img=case["img"], txt=case["txt"], vec=case["vec"], pe=pe,
+                               concepts=case["concepts"], concept_vec=case["concept_vec"], concept_pe=cpe)
+    hm_fn = ref["compute_heatmaps_from_vectors"]
+    st = {k: v[None, None] for k, v in d.items()}  # [time=1, layers=1, batch, ...]
+    hm_out = hm_fn(st["output_space_image_vectors"], st["output_space_concept_vectors"],
+                   layer_indices=[0], timesteps=[0], softmax=True)
+    hm_cross = hm_fn(st["cross_attention_image_vectors"], st["cross_attention_concept_vectors"],
+                     layer_indices=[0], timesteps=[0], softmax=True)
+    logits_out = torch.einsum("bpd,bcd->bcp", d["output_space_image_vectors"], d["output_space_concept_vectors"])
+    ciq = d["cross_attention_image_vectors"].permute(0, 2, 1, 3).reshape(1, -1, H)
+    ccq = d["cross_attention_concept_vectors"].permute(0, 2, 1, 3).reshape(1, -1, H)
+    logits_cross = torch.einsum("bpd,bcd->bcp", ciq, ccq)
+    rows = case["sample_rows"]
+    arrays = dict(
+        heatmap_output_space=hm_out.numpy(), heatmap_cross_attention=hm_cross.numpy(),
+        logits_output_space=logits_out.numpy(), logits_cross_attention=logits_cross.numpy(),
+        concept_attn=d["output_space_concept_vectors"].numpy(),
+        concept_q=d["cross_attention_concept_vectors"].numpy(),
+        img_attn_rows=d["output_space_image_vectors"][0, rows].numpy(),
+        img_q_rows=d["cross_attention_image_vectors"][0, :, rows].numpy(),
+        img_out_rows=img[0, rows].numpy(), txt_out=txt[0, ::8].numpy(), concepts_out=con.numpy(),
+        sample_rows=rows.numpy(),
+        img_out_checksum=_checksum(img), in_checksum=_checksum(case["img"]),
+        w_checksum=_checksum(sd["img_mlp.2.weight"]),
+    )
+    np.savez_compressed(os.path.join(out_dir, "block_full.npz"), **arrays)
+    print("block_full heat range", hm_out.min().item(), hm_out.max().item(),
+          "cross", hm_cross.min().item(), hm_cross.max().item())
+    del blk, sd
+    # ---------------- single block
+    sd = synthetic_state_dict(p, seed=0, prefix="single_blocks.0.")
+    sd = {k[len("single_blocks.0."):]: v.bfloat16().float() for k, v in sd.items()}
+    sblk = ref["ModifiedSingleStreamBlock"](H, NH, mlp_ratio=p.mlp_ratio).eval()
+    sblk.load_state_dict(sd, strict=True)
+    x = torch.cat((case["txt"], case["img"]), 1)
+    with torch.no_grad():
+        y = sblk(x, vec=case["vec"], pe=pe)
+    srows = torch.cat((torch.arange(0, 256, 16), 256 + rows))
+    np.savez_compressed(os.path.join(out_dir, "single_full.npz"), out_rows=y[0, srows].numpy(),
+                        sample_rows=srows.numpy(), out_checksum=_checksum(y))
+    print("single_full done")
+
+
+def heatmap_kat(ref, out_dir):
+    fn = ref["compute_heatmaps_from_vectors"]
+    g = torch.Generator().manual_seed(11)
+    iv = torch.randn(3, 5, 1, 4096, 16, generator=g)
+    cv = torch.randn(3, 5, 1, 4, 16, generator=g)
+    a = fn(iv, cv, layer_indices=[1, 3, 4], timesteps=[0, 2], softmax=True)
+    b = fn(iv, cv, layer_indices=[2], timesteps=[1], softmax=True, normalize_concepts=True)
+    iv6 = torch.randn(2, 2, 1, 2, 4096, 8, generator=g)
+    cv6 = torch.randn(2, 2, 1, 2, 5, 8, generator=g)
+    c = fn(iv6, cv6, layer_indices=[0, 1], timesteps=[0, 1], softmax=True)
+    np.savez_compressed(os.path.join(out_dir, "heatmap_kat.npz"),
+                        iv=iv.half().numpy(), cv=cv.half().numpy(), iv6=iv6.half().numpy(),
+                        cv6=cv6.half().numpy(),
+                        out_a=fn(iv.half().float(), cv.half().float(), layer_indices=[1, 3, 4],
+                                 timesteps=[0, 2], softmax=True).numpy(),
+                        out_b=fn(iv.half().float(), cv.half().float(), layer_indices=[2], timesteps=[1],
+                                 softmax=True, normalize_concepts=True).numpy(),
+                        out_c=fn(iv6.half().float(), cv6.half().float(), layer_indices=[0, 1],
+                                 timesteps=[0, 1], softmax=True).numpy())
+    print("heatmap_kat", a.shape, b.shape, c.shape)
+
+
+def sampler(ref, out_dir):
+    from conceptattention_amd.params import tiny_params
+    from conceptattention_amd.weights import synthetic_state_dict, synthetic_inputs
+    s = ref["sampling"]
+    arrays = {
+        "schedule_schnell_4": np.array(s.get_schedule(4, 4096, shift=False)),
+        "schedule_dev_50_4096": np.array(s.get_schedule(50, 4096, shift=True)),
+        "schedule_dev_28_1024": np.array(s.get_schedule(28, 1024, shift=True)),
+    }
+    x = torch.arange(16 * 8 * 12, dtype=torch.float32).reshape(1, 16, 8, 12)
+    from einops import rearrange
+    packed = rearrange(x, "b c (h ph) (w pw) -> b (h w) (c ph pw)", ph=2, pw=2)
+    arrays["patchify_in"] = x.numpy()
+    arrays["patchify_out"] = packed.numpy()
+    arrays["unpack_out"] = s.unpack(packed, 64, 96).numpy()
+    # tiny 2-step denoise + heatmaps through the reference sampler (64x64 patches so that the
+    # reference's hard-coded 64x64 reshape, concept_attention_pipeline.py:85-90, is valid)
+    p = tiny_params(depth=2, depth_single_blocks=1)
+    sd = synthetic_state_dict(p, seed=3)
+    model = ref["ModifiedFluxDiT"](_ref_params(ref, p)).eval()
+    model.load_state_dict(sd, strict=True)
+    inp = synthetic_inputs(p, 1024, 1024, n_txt=8, n_concepts=3, seed=4)
+    img = rearrange(inp["latent"], "b c (h ph) (w pw) -> b (h w) (c ph pw)", ph=2, pw=2)
+    ts = s.get_schedule(2, img.shape[1], shift=False)
+    with torch.no_grad():
+        out, _, d = s.denoise(model, img=img, img_ids=inp["img_ids"], txt=inp["txt"],
+                              txt_ids=inp["txt_ids"], vec=inp["vec"], timesteps=ts, guidance=0.0,
+                              concepts=inp["concepts"], concept_ids=inp["concept_ids"],
+                              concept_vec=inp["concept_vec"])
+    fn = ref["compute_heatmaps_from_vectors"]
+    arrays["denoise_img_rows"] = out[0, ::64].numpy()
+    arrays["denoise_img_checksum"] = _checksum(out)
+    arrays["denoise_heatmaps"] = fn(d["output_space_image_vectors"], d["output_space_concept_vectors"],
+                                    layer_indices=[0, 1], timesteps=[0, 1], softmax=True).numpy()
+    arrays["denoise_cross_maps"] = fn(d["cross_attention_image_vectors"],
+                                      d["cross_attention_concept_vectors"],
+                                      layer_indices=[1], timesteps=[0, 1], softmax=True).numpy()
+    np.savez_compressed(os.path.join(out_dir, "sampler.npz"), **arrays)
+    print("sampler done", arrays["schedule_schnell_4"])
+
+
+def main():
+    torch.set_num_threads(8)
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    ref = _import_reference()
+    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "full"]
+    if "tiny" in which:
+        tiny_model(ref, out_dir, False, "tiny_schnell.npz")
+        tiny_model(ref, out_dir, True, "tiny_dev.npz")
+    if "ablation" in which:
+        tiny_ablation(ref, out_dir)
+    if "heatmap" in which:
+        heatmap_kat(ref, out_dir)
+    if "sampler" in which:
+        sampler(ref, out_dir)
+    if "full" in which:
+        full_blocks(ref, out_dir)
+
+
+if __name__ == "__main__":
+    main()
