@@ -1,0 +1,45 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libconceptattn.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/conceptattn.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CA_WAVE 64
+
+typedef const __attribute__((address_space(1))) void *ca_gptr;
+typedef __attribute__((address_space(3))) void *ca_lptr;
+
+// Asynchronous 16-byte-per-lane global -> LDS copy (global_load_lds_dwordx4).  The LDS
+// destination is wave-uniform base + lane*16; the global source is per lane.
+__device__ __forceinline__ void ca_glds16(const void *gsrc, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((ca_gptr)gsrc, (ca_lptr)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float ca_bf2f(bf16 x) { return (float)x; }
+
+// pack two floats into one dword of 2 x bf16 (RNE; hipcc emits v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t ca_pack2(float lo, float hi) {
+  bf16x2 v = {(bf16)lo, (bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ float ca_gelu_tanh(float x) {
+  // nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float e = __expf(2.0f * u);
+  const float t = 1.0f - 2.0f / (e + 1.0f);  // tanh(u); e=inf -> 1, e=0 -> -1
+  return 0.5f * x * (1.0f + t);
+}
+
+__device__ __forceinline__ float ca_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// host-side error plumbing (ca_api.cpp)
+void ca_set_error(const char *fmt, ...);

@@ -1,0 +1,380 @@
+// Grouped bf16 GEMM with fused epilogues for gfx950 (MI355X).
+//
+//   out[m,n] = epi( sum_k A[m,k] * W[n,k] + bias[n] )        A:[M,K]  W:[N,K] (nn.Linear layout)
+//
+// Design (MI355X-first, see DESIGN.md "GEMM"):
+//  * one workgroup = 8 waves (2 along M x 4 along N), 1 workgroup per CU, tile BM x BN x 64 with
+//    BM = 256, BN = 64*N_REP; fp32 accumulators live in registers (v_mfma_f32_16x16x32_bf16).
+//  * operands are staged HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip) into a
+//    2-deep ring; the LDS image is lane-linear, so the bank-conflict swizzle
+//    (16-byte chunk ^= (row>>1)&7 on 128-byte rows) is applied to the per-lane SOURCE address and
+//    again on the ds_read_b128 side.
+//  * the MFMA is issued "transposed" (W fragment as the A operand, activation fragment as B) and
+//    the W rows of a wave are staged in a permuted order, so that every lane ends up holding
+//    4*N_REP CONTIGUOUS output columns of one row: the epilogue (bias, GELU, gate*x+residual)
+//    runs in registers and stores 16-byte pieces, 128 contiguous bytes per 4 lanes.
+//  * several problems share one launch (image stream + text/concept stream of a double block),
+//    tile ids are remapped so that the 32 workgroups that share an XCD (same blockIdx % 8) work
+//    on an 8(M) x 4(N) patch of tiles and reuse each other's panels in that XCD's L2.
+#include "ca_common.h"
+
+namespace {
+
+struct GemmLaunch {
+  ca_gemm_problem p[CA_GEMM_MAX_PROBLEMS];
+  int32_t ntiles[CA_GEMM_MAX_PROBLEMS];
+  int32_t mt[CA_GEMM_MAX_PROBLEMS];
+  int32_t nt[CA_GEMM_MAX_PROBLEMS];
+};
+
+template <int M_REP, int N_REP>
+struct Cfg {
+  static constexpr int BM = 2 * 16 * M_REP;
+  static constexpr int BN = 4 * 16 * N_REP;
+  static constexpr int BK = 64;
+  static constexpr int ROW_BYTES = BK * 2;
+  static constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static constexpr int NLOAD = (BM + BN) / 64;  // global_load_lds per wave per K tile
+  static_assert(BM % 64 == 0, "A/W boundary must be wave-instruction aligned");
+};
+
+constexpr int GROUP_M = 8;
+
+template <int M_REP, int N_REP>
+__global__ __launch_bounds__(512, 2) void ca_gemm_kernel(const GemmLaunch L) {
+  using C = Cfg<M_REP, N_REP>;
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- tile id: XCD-contiguous remap (bijective for any grid size), then grouped-M order
+  const int nblk = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
+  int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int prob = (lid >= L.ntiles[0]) ? 1 : 0;
+  if (prob) lid -= L.ntiles[0];
+  const ca_gemm_problem &P = L.p[prob];
+  const int MT = L.mt[prob], NT = L.nt[prob];
+  const int grp = lid / (GROUP_M * NT);
+  const int first_m = grp * GROUP_M;
+  const int gm = min(GROUP_M, MT - first_m);
+  const int in_grp = lid - grp * GROUP_M * NT;
+  const int m0 = (first_m + in_grp % gm) * C::BM;
+  const int n0 = (in_grp / gm) * C::BN;
+
+  const int M = P.M, K = P.K;
+  const char *Ab = (const char *)P.A;
+  const char *Wb = (const char *)P.W;
+
+  // ---- per-lane source byte offsets of the staging loads (k = 0)
+  uint32_t src_off[C::NLOAD];
+#pragma unroll
+  for (int i = 0; i < C::NLOAD; ++i) {
+    const int rr = i * 64 + wave * 8 + (lane >> 3);
+    const int cp = lane & 7;
+    if (i * 64 < C::BM) {
+      const int rho = rr;
+      const int c = cp ^ ((rho >> 1) & 7);
+      const int row = min(m0 + rho, M - 1);
+      src_off[i] = ((uint32_t)row * (uint32_t)P.lda + (uint32_t)c * 8u) * 2u;
+    } else {
+      const int rho = rr - C::BM;
+      const int c = cp ^ ((rho >> 1) & 7);
+      const int wloc = rho % (16 * N_REP);
+      const int wbase = rho - wloc;
+      const int j = wloc >> 4, a = (wloc >> 2) & 3, b = wloc & 3;
+      const int n = n0 + wbase + 4 * N_REP * a + 4 * j + b;
+      src_off[i] = ((uint32_t)n * (uint32_t)P.ldw + (uint32_t)c * 8u) * 2u;
+    }
+  }
+
+  auto stage = [&](int buf, int kt) {
+    const uint32_t kb = (uint32_t)kt * (C::BK * 2);
+    char *base = smem + buf * C::STAGE_BYTES + wave * 8 * C::ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::NLOAD; ++i) {
+      const char *src = ((i * 64 < C::BM) ? Ab : Wb) + src_off[i] + kb;
+      ca_glds16(src, base + i * 64 * C::ROW_BYTES);
+    }
+  };
+
+  f32x4 acc[M_REP][N_REP];
+#pragma unroll
+  for (int i = 0; i < M_REP; ++i)
+#pragma unroll
+    for (int j = 0; j < N_REP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row (lane&15), 16-byte chunk ((lane>>4) ^ row>>1), k-step s flips bit 6
+  const int lane_off = (lane & 15) * C::ROW_BYTES + ((((lane >> 4) ^ ((lane & 15) >> 1)) & 7) << 4);
+  const int a_off = wm * 16 * M_REP * C::ROW_BYTES + lane_off;
+  const int w_off = (C::BM + wn * 16 * N_REP) * C::ROW_BYTES + lane_off;
+
+  auto compute = [&](int buf) {
+    const char *sb = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 wf[N_REP], af[M_REP];
+#pragma unroll
+      for (int j = 0; j < N_REP; ++j)
+        wf[j] = *(const bf16x8 *)(sb + ((w_off + j * 16 * C::ROW_BYTES) ^ (s * 64)));
+#pragma unroll
+      for (int i = 0; i < M_REP; ++i)
+        af[i] = *(const bf16x8 *)(sb + ((a_off + i * 16 * C::ROW_BYTES) ^ (s * 64)));
+#pragma unroll
+      for (int i = 0; i < M_REP; ++i)
+#pragma unroll
+        for (int j = 0; j < N_REP; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: 2-deep LDS ring, next tile's global_load_lds in flight under the MFMAs
+  const int nk = K / C::BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    stage(cur ^ 1, kt + 1);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  compute(cur);
+
+  // ---- epilogue.  acc[i][j][r] = C[m][n]:  m = m0 + wm*16*M_REP + 16*i + (lane&15)
+  //                                          n = n0 + wn*16*N_REP + 4*N_REP*(lane>>4) + 4*j + r
+  const int g = lane >> 4;
+  const int nb = n0 + wn * 16 * N_REP + 4 * N_REP * g;
+  int epi = P.epilogue;
+  char *outb = (char *)P.out;
+  int ldo = P.ldc;
+  int ncol = nb;
+  if (epi == CA_EPI_SPLIT_GELU) {
+    if (n0 >= P.n_split) {
+      epi = CA_EPI_GELU_TANH;
+      outb = (char *)P.out2;
+      ldo = P.ld2;
+      ncol = nb - P.n_split;
+    } else {
+      epi = CA_EPI_BIAS;
+    }
+  }
+  float bias[4 * N_REP];
+#pragma unroll
+  for (int t = 0; t < 4 * N_REP; ++t) bias[t] = 0.f;
+  if (P.bias) {
+    const bf16 *bp = (const bf16 *)P.bias + nb;
+#pragma unroll
+    for (int j = 0; j < N_REP; ++j) {
+      const bf16x4 b4 = *(const bf16x4 *)(bp + 4 * j);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[4 * j + r] = (float)b4[r];
+    }
+  }
+  const int mrow0 = m0 + wm * 16 * M_REP + (lane & 15);
+
+  if (epi == CA_EPI_GATE_RESIDUAL) {
+    float gate_a[4 * N_REP], gate_b[4 * N_REP];
+    const float *g1 = P.gate + nb;
+    const float *g2 = (P.gate2 ? P.gate2 : P.gate) + nb;
+#pragma unroll
+    for (int j = 0; j < N_REP; ++j) {
+      const f32x4 ga = *(const f32x4 *)(g1 + 4 * j);
+      const f32x4 gb = *(const f32x4 *)(g2 + 4 * j);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gate_a[4 * j + r] = ga[r];
+        gate_b[4 * j + r] = gb[r];
+      }
+    }
+    const char *resb = (const char *)P.resid;
+#pragma unroll
+    for (int i = 0; i < M_REP; ++i) {
+      const int m = mrow0 + 16 * i;
+      if (m < M) {
+        const bool first = m < P.gate_rows;
+        const uint2 *rp = (const uint2 *)(resb + ((size_t)m * P.ldr + nb) * 2);
+        uint2 *op = (uint2 *)(outb + ((size_t)m * ldo + ncol) * 2);
+        uint2 res[N_REP];
+#pragma unroll
+        for (int j = 0; j < N_REP; ++j) res[j] = rp[j];
+#pragma unroll
+        for (int j = 0; j < N_REP; ++j) {
+          float v[4];
+          const bf16x4 r4 = __builtin_bit_cast(bf16x4, res[j]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gt = first ? gate_a[4 * j + r] : gate_b[4 * j + r];
+            v[r] = (float)r4[r] + gt * (acc[i][j][r] + bias[4 * j + r]);
+          }
+          op[j] = make_uint2(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]));
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < M_REP; ++i) {
+      const int m = mrow0 + 16 * i;
+      if (m < M) {
+        uint2 *op = (uint2 *)(outb + ((size_t)m * ldo + ncol) * 2);
+#pragma unroll
+        for (int j = 0; j < N_REP; ++j) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][j][r] + bias[4 * j + r];
+            if (epi == CA_EPI_GELU_TANH) v[r] = ca_gelu_tanh(v[r]);
+          }
+          op[j] = make_uint2(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]));
+        }
+      }
+    }
+  }
+}
+
+template <int M_REP, int N_REP>
+int launch(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
+  using C = Cfg<M_REP, N_REP>;
+  static bool attr_done = false;  // idempotent; a race only repeats the call
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_kernel<M_REP, N_REP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) {
+      ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+      return CA_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((ca_gemm_kernel<M_REP, N_REP>), dim3(total_tiles), dim3(512), C::LDS_BYTES, stream, L);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ca_set_error("ca_gemm_bf16: launch failed: %s", hipGetErrorString(e));
+    return CA_ERR_LAUNCH;
+  }
+  return CA_OK;
+}
+
+int tile_n_of(int tile) {
+  switch (tile) {
+    case CA_TILE_256x256: return 256;
+    case CA_TILE_256x192: return 192;
+    case CA_TILE_256x128: return 128;
+    case CA_TILE_256x64: return 64;
+    default: return 0;
+  }
+}
+
+// Pick the tile width that wastes the fewest CU-rounds (256 CUs, one workgroup per CU).
+int auto_tile(const ca_gemm_problem *p, int n) {
+  static const int cands[] = {CA_TILE_256x256, CA_TILE_256x192, CA_TILE_256x128, CA_TILE_256x64};
+  int best = 0;
+  double best_cost = 1e300;
+  for (int c : cands) {
+    const int bn = tile_n_of(c);
+    bool ok = true;
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+      if (p[i].N % bn) ok = false;
+      if (p[i].epilogue == CA_EPI_SPLIT_GELU && p[i].n_split % bn) ok = false;
+      tiles += (long)((p[i].M + 255) / 256) * (p[i].N / bn);
+    }
+    if (!ok) continue;
+    const long rounds = (tiles + 255) / 256;
+    // per-tile time ~ BN plus a fixed per-tile overhead that penalises narrow tiles
+    const double cost = (double)rounds * (bn + 48.0);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = c;
+    }
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
+                            ca_stream_t stream) {
+  if (!problems || n_problems < 1 || n_problems > CA_GEMM_MAX_PROBLEMS) {
+    ca_set_error("ca_gemm_bf16: n_problems=%d out of range [1,%d]", n_problems, CA_GEMM_MAX_PROBLEMS);
+    return CA_ERR_ARG;
+  }
+  if (tile == CA_TILE_AUTO) tile = auto_tile(problems, n_problems);
+  const int bn = tile_n_of(tile);
+  if (!bn) {
+    ca_set_error("ca_gemm_bf16: no tile configuration fits (tile=%d)", tile);
+    return CA_ERR_ARG;
+  }
+  GemmLaunch L = {};
+  int total = 0;
+  for (int i = 0; i < n_problems; ++i) {
+    const ca_gemm_problem &p = problems[i];
+    if (!p.A || !p.W || !p.out || p.M < 1 || p.N < 1 || p.K < 64) {
+      ca_set_error("ca_gemm_bf16[%d]: null pointer or empty shape (M=%d N=%d K=%d)", i, p.M, p.N, p.K);
+      return CA_ERR_ARG;
+    }
+    if (p.K % 64 || p.N % bn || p.lda % 8 || p.ldw % 8 || p.ldc % 8) {
+      ca_set_error("ca_gemm_bf16[%d]: need K%%64==0, N%%%d==0, ld%%8==0 (M=%d N=%d K=%d lda=%d ldw=%d ldc=%d)", i,
+                   bn, p.M, p.N, p.K, p.lda, p.ldw, p.ldc);
+      return CA_ERR_ARG;
+    }
+    if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out | (uintptr_t)p.bias) & 15) {
+      ca_set_error("ca_gemm_bf16[%d]: pointers must be 16-byte aligned", i);
+      return CA_ERR_ARG;
+    }
+    if (p.lda < p.K || p.ldw < p.K) {
+      ca_set_error("ca_gemm_bf16[%d]: lda/ldw smaller than K", i);
+      return CA_ERR_ARG;
+    }
+    if ((uint64_t)p.M * p.lda * 2 >= (1ull << 32) || (uint64_t)p.N * p.ldw * 2 >= (1ull << 32)) {
+      ca_set_error("ca_gemm_bf16[%d]: operand larger than 4 GiB", i);
+      return CA_ERR_ARG;
+    }
+    switch (p.epilogue) {
+      case CA_EPI_BIAS:
+      case CA_EPI_GELU_TANH:
+        if (p.ldc < p.N) { ca_set_error("ca_gemm_bf16[%d]: ldc < N", i); return CA_ERR_ARG; }
+        break;
+      case CA_EPI_GATE_RESIDUAL:
+        if (!p.resid || !p.gate || p.ldr % 8 || p.ldc < p.N || ((uintptr_t)p.resid & 15) ||
+            ((uintptr_t)p.gate & 15) || ((uintptr_t)p.gate2 & 15) || (p.gate_rows < p.M && !p.gate2)) {
+          ca_set_error("ca_gemm_bf16[%d]: GATE_RESIDUAL needs resid, gate (and gate2 when gate_rows < M), 16-byte aligned", i);
+          return CA_ERR_ARG;
+        }
+        break;
+      case CA_EPI_SPLIT_GELU:
+        if (!p.out2 || p.n_split <= 0 || p.n_split >= p.N || p.n_split % bn || p.ld2 % 8 ||
+            ((uintptr_t)p.out2 & 15) || p.ldc < p.n_split || p.ld2 < p.N - p.n_split) {
+          ca_set_error("ca_gemm_bf16[%d]: SPLIT_GELU needs out2 and 0 < n_split < N, n_split %% %d == 0", i, bn);
+          return CA_ERR_ARG;
+        }
+        break;
+      default:
+        ca_set_error("ca_gemm_bf16[%d]: unknown epilogue %d", i, p.epilogue);
+        return CA_ERR_ARG;
+    }
+    L.p[i] = p;
+    L.mt[i] = (p.M + 255) / 256;
+    L.nt[i] = p.N / bn;
+    L.ntiles[i] = L.mt[i] * L.nt[i];
+    total += L.ntiles[i];
+  }
+  if (n_problems == 1) {
+    L.ntiles[1] = 0;
+    L.mt[1] = L.nt[1] = 1;
+    L.p[1] = L.p[0];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  switch (tile) {
+    case CA_TILE_256x256: return launch<8, 4>(L, total, s);
+    case CA_TILE_256x192: return launch<8, 3>(L, total, s);
+    case CA_TILE_256x128: return launch<8, 2>(L, total, s);
+    default: return launch<8, 1>(L, total, s);
+  }
+}

@@ -1,0 +1,395 @@
+// HBM-bound row kernels of the ConceptAttention path for gfx950: LayerNorm+modulation,
+// QK-RMSNorm+RoPE, small-batch GEMV (weight streaming), concept heat-map reduction, Euler axpy.
+// All use 16-byte-per-lane coalesced accesses and fp32 arithmetic; none of them is shaped into
+// an MFMA product (they are bandwidth-bound: see DESIGN.md for bytes per unit).
+#include "ca_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// out = (1 + scale) * LayerNorm(x) + shift ; one wave per row, row kept in registers.
+struct LnArgs {
+  ca_mod_segment seg[CA_MAX_SEGMENTS];
+  int32_t n_segs;
+};
+constexpr int LN_MAXCH = 8;  // H <= 8 * 512
+
+__global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const bf16 *__restrict__ x, int ldx,
+                                                             bf16 *__restrict__ out, int ldo, int M, int H,
+                                                             float eps, const LnArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  int si = 0;
+#pragma unroll
+  for (int s = 0; s < CA_MAX_SEGMENTS - 1; ++s)
+    if (s + 1 < A.n_segs && row >= A.seg[s].row_end) si = s + 1;
+  const float *shift = A.seg[si].shift;
+  const float *scale = A.seg[si].scale;
+
+  const bf16 *xr = x + (size_t)row * ldx;
+  float v[LN_MAXCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXCH; ++c) {
+    const int k = c * 512 + lane * 8;
+    if (k < H) {
+      const bf16x8 t = *(const bf16x8 *)(xr + k);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] = (float)t[j];
+        sum += v[c][j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXCH; ++c) {
+    const int k = c * 512 + lane * 8;
+    if (k < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[c][j] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+  bf16 *orow = out + (size_t)row * ldo;
+#pragma unroll
+  for (int c = 0; c < LN_MAXCH; ++c) {
+    const int k = c * 512 + lane * 8;
+    if (k < H) {
+      const f32x4 sc0 = *(const f32x4 *)(scale + k), sc1 = *(const f32x4 *)(scale + k + 4);
+      const f32x4 sh0 = *(const f32x4 *)(shift + k), sh1 = *(const f32x4 *)(shift + k + 4);
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = (1.f + sc0[j]) * ((v[c][j] - mean) * rstd) + sh0[j];
+        y[4 + j] = (1.f + sc1[j]) * ((v[c][4 + j] - mean) * rstd) + sh1[j];
+      }
+      *(uint4 *)(orow + k) =
+          make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// QK-RMSNorm + RoPE in place; 16 lanes per (row, q|k, head) unit, 8 elements (4 rotation pairs)/lane
+struct NormArgs {
+  ca_norm_segment seg[CA_MAX_SEGMENTS];
+  int32_t n_segs;
+};
+
+__global__ __launch_bounds__(256) void ca_qknorm_rope_kernel(bf16 *__restrict__ qkv, int ld, int M, int NH,
+                                                             const float *__restrict__ rope,
+                                                             bf16 *__restrict__ q_prerope, int ldp,
+                                                             const NormArgs A) {
+  const int t16 = threadIdx.x & 15;
+  const long unit = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const long nunits = (long)M * 2 * NH;
+  const bool valid = unit < nunits;
+  const long u = valid ? unit : nunits - 1;  // keep all lanes alive for the shuffles
+  const int row = (int)(u / (2 * NH));
+  const int rem = (int)(u % (2 * NH));
+  const int which = rem / NH, head = rem % NH;
+  int si = 0;
+#pragma unroll
+  for (int s = 0; s < CA_MAX_SEGMENTS - 1; ++s)
+    if (s + 1 < A.n_segs && row >= A.seg[s].row_end) si = s + 1;
+  const bf16 *scale = (const bf16 *)(which ? A.seg[si].k_scale : A.seg[si].q_scale);
+
+  bf16 *p = qkv + (size_t)row * ld + (size_t)which * NH * 128 + head * 128 + t16 * 8;
+  const bf16x8 xv = *(const bf16x8 *)p;
+  const bf16x8 sv = *(const bf16x8 *)(scale + t16 * 8);
+  float x[8];
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    x[j] = (float)xv[j];
+    sq += x[j] * x[j];
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rrms = rsqrtf(sq * (1.0f / 128.0f) + 1e-6f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = x[j] * rrms * (float)sv[j];
+  if (!valid) return;
+  if (q_prerope && which == 0) {
+    *(uint4 *)(q_prerope + (size_t)row * ldp + head * 128 + t16 * 8) =
+        make_uint4(ca_pack2(x[0], x[1]), ca_pack2(x[2], x[3]), ca_pack2(x[4], x[5]), ca_pack2(x[6], x[7]));
+  }
+  // rope table row: [64 pairs][cos, sin]; this lane owns pairs 4*t16 .. 4*t16+3
+  const float *rp = rope + (size_t)row * 128 + t16 * 8;
+  const f32x4 r0 = *(const f32x4 *)rp, r1 = *(const f32x4 *)(rp + 4);
+  const float cs[4] = {r0[0], r0[2], r1[0], r1[2]};
+  const float sn[4] = {r0[1], r0[3], r1[1], r1[3]};
+  float y[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    y[2 * i] = cs[i] * x[2 * i] - sn[i] * x[2 * i + 1];
+    y[2 * i + 1] = sn[i] * x[2 * i] + cs[i] * x[2 * i + 1];
+  }
+  *(uint4 *)p = make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+}
+
+// ------------------------------------------------------------------------------------------
+// out[v,n] (+)= sum_k f(x[v,k]) W[n,k] + bias[n]; one wave per output row n, x staged in LDS (fp32)
+template <int NV>
+__global__ __launch_bounds__(256) void ca_gemv_kernel(const float *__restrict__ x, int ldx,
+                                                      const bf16 *__restrict__ W, const bf16 *__restrict__ bias,
+                                                      float *__restrict__ out, int ldo, int N, int K, int silu,
+                                                      int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *xs = (float *)smem_raw;  // [NV][K]
+  for (int i = threadIdx.x; i < NV * K; i += 256) {
+    const int v = i / K, k = i - v * K;
+    const float t = x[(size_t)v * ldx + k];
+    xs[i] = silu ? ca_silu(t) : t;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+    const bf16 *wr = W + (size_t)n * K;
+    float acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      const bf16x8 w8 = *(const bf16x8 *)(wr + k);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const f32x4 a = *(const f32x4 *)(xs + v * K + k), b = *(const f32x4 *)(xs + v * K + k + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[v] = fmaf((float)w8[j], a[j], acc[v]);
+          acc[v] = fmaf((float)w8[4 + j], b[j], acc[v]);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = wave_sum(acc[v]);
+    if (lane == 0) {
+      const float b = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float *o = out + (size_t)v * ldo + n;
+        const float r = acc[v] + b;
+        *o = accumulate ? (*o + r) : r;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// logits[c,p] = <img_vec[p,:], con_vec[c,:]> for CC concepts per pass; one wave per patch
+template <int CC>
+__global__ __launch_bounds__(256) void ca_heatmap_logits_kernel(const bf16 *__restrict__ img, int ldi,
+                                                                const bf16 *__restrict__ con, int ldc, int L,
+                                                                int C, int c0, int dim,
+                                                                float *__restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16 *cs = (bf16 *)smem_raw;  // [CC][dim]
+  for (int i = threadIdx.x * 8; i < CC * dim; i += 256 * 8) {
+    const int c = i / dim, k = i - c * dim;
+    const int cr = min(c0 + c, C - 1);
+    *(uint4 *)(cs + i) = *(const uint4 *)(con + (size_t)cr * ldc + k);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int p = blockIdx.x * 4 + wave; p < L; p += gridDim.x * 4) {
+    const bf16 *ir = img + (size_t)p * ldi;
+    float acc[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+    for (int k = lane * 8; k < dim; k += 512) {
+      const bf16x8 a = *(const bf16x8 *)(ir + k);
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        const bf16x8 b = *(const bf16x8 *)(cs + c * dim + k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[c] = fmaf((float)a[j], (float)b[j], acc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = wave_sum(acc[c]);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < CC; ++c)
+        if (c0 + c < C) logits[(size_t)(c0 + c) * L + p] = acc[c];
+    }
+  }
+}
+
+// acc[c,p] += weight * softmax_c(logits[:,p])
+__global__ __launch_bounds__(256) void ca_heatmap_softmax_kernel(const float *__restrict__ logits, int C, int L,
+                                                                 float weight, float *__restrict__ acc) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= L) return;
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[(size_t)c * L + p]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += __expf(logits[(size_t)c * L + p] - mx);
+  const float inv = weight / sum;
+  for (int c = 0; c < C; ++c) acc[(size_t)c * L + p] += __expf(logits[(size_t)c * L + p] - mx) * inv;
+}
+
+__global__ __launch_bounds__(256) void ca_axpy_kernel(bf16 *__restrict__ x, const bf16 *__restrict__ y, float a,
+                                                      long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    const bf16x8 xv = *(const bf16x8 *)(x + i), yv = *(const bf16x8 *)(y + i);
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = fmaf(a, (float)yv[j], (float)xv[j]);
+    *(uint4 *)(x + i) = make_uint4(ca_pack2(r[0], r[1]), ca_pack2(r[2], r[3]), ca_pack2(r[4], r[5]), ca_pack2(r[6], r[7]));
+  } else {
+    for (long j = i; j < n; ++j) x[j] = (bf16)fmaf(a, (float)y[j], (float)x[j]);
+  }
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ca_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return CA_ERR_LAUNCH;
+  }
+  return CA_OK;
+}
+
+}  // namespace
+
+extern "C" int ca_ln_modulate_bf16(const void *x, int32_t ldx, void *out, int32_t ldo, int32_t M, int32_t H,
+                                   const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream) {
+  if (!x || !out || !segs || M < 1 || H < 8 || H % 8 || H > LN_MAXCH * 512 || n_segs < 1 ||
+      n_segs > CA_MAX_SEGMENTS || ldx % 8 || ldo % 8 || ldx < H || ldo < H ||
+      (((uintptr_t)x | (uintptr_t)out) & 15)) {
+    ca_set_error("ca_ln_modulate_bf16: bad arguments (M=%d H=%d n_segs=%d ldx=%d ldo=%d; need H%%8==0, H<=%d)", M, H,
+                 n_segs, ldx, ldo, LN_MAXCH * 512);
+    return CA_ERR_ARG;
+  }
+  LnArgs A = {};
+  A.n_segs = n_segs;
+  int prev = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    if (!segs[i].shift || !segs[i].scale || segs[i].row_end < prev ||
+        (((uintptr_t)segs[i].shift | (uintptr_t)segs[i].scale) & 15)) {
+      ca_set_error("ca_ln_modulate_bf16: segment %d invalid (row_end must be non-decreasing, vectors 16-byte aligned)", i);
+      return CA_ERR_ARG;
+    }
+    prev = segs[i].row_end;
+    A.seg[i] = segs[i];
+  }
+  if (prev < M) {
+    ca_set_error("ca_ln_modulate_bf16: segments cover %d rows, M=%d", prev, M);
+    return CA_ERR_ARG;
+  }
+  hipLaunchKernelGGL(ca_ln_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x,
+                     ldx, (bf16 *)out, ldo, M, H, eps, A);
+  return check_launch("ca_ln_modulate_bf16");
+}
+
+extern "C" int ca_qknorm_rope_bf16(void *qkv, int32_t ld, int32_t M, int32_t num_heads,
+                                   const ca_norm_segment *segs, int32_t n_segs, const float *rope_cos_sin,
+                                   void *q_prerope, int32_t ldp, ca_stream_t stream) {
+  if (!qkv || !segs || !rope_cos_sin || M < 1 || num_heads < 1 || n_segs < 1 || n_segs > CA_MAX_SEGMENTS ||
+      ld % 8 || ld < 3 * num_heads * 128 || (((uintptr_t)qkv | (uintptr_t)rope_cos_sin | (uintptr_t)q_prerope) & 15) ||
+      (q_prerope && (ldp % 8 || ldp < num_heads * 128))) {
+    ca_set_error("ca_qknorm_rope_bf16: bad arguments (M=%d heads=%d ld=%d n_segs=%d)", M, num_heads, ld, n_segs);
+    return CA_ERR_ARG;
+  }
+  NormArgs A = {};
+  A.n_segs = n_segs;
+  int prev = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    if (!segs[i].q_scale || !segs[i].k_scale || segs[i].row_end < prev ||
+        (((uintptr_t)segs[i].q_scale | (uintptr_t)segs[i].k_scale) & 15)) {
+      ca_set_error("ca_qknorm_rope_bf16: segment %d invalid", i);
+      return CA_ERR_ARG;
+    }
+    prev = segs[i].row_end;
+    A.seg[i] = segs[i];
+  }
+  if (prev < M) {
+    ca_set_error("ca_qknorm_rope_bf16: segments cover %d rows, M=%d", prev, M);
+    return CA_ERR_ARG;
+  }
+  const long units = (long)M * 2 * num_heads;
+  hipLaunchKernelGGL(ca_qknorm_rope_kernel, dim3((unsigned)((units + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                     (bf16 *)qkv, ld, M, num_heads, rope_cos_sin, (bf16 *)q_prerope, ldp, A);
+  return check_launch("ca_qknorm_rope_bf16");
+}
+
+extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void *W, const void *bias, float *out,
+                            int32_t ldo, int32_t N, int32_t K, int32_t silu_input, int32_t accumulate,
+                            ca_stream_t stream) {
+  if (!x || !W || !out || nv < 1 || nv > 4 || N < 1 || K < 8 || K % 8 || K > 4096 || ldx < K || ldo < N ||
+      (((uintptr_t)W) & 15)) {
+    ca_set_error("ca_gemv_bf16: bad arguments (nv=%d N=%d K=%d; need 1<=nv<=4, K%%8==0, K<=4096)", nv, N, K);
+    return CA_ERR_ARG;
+  }
+  const int grid = (N + 3) / 4 < 4096 ? (N + 3) / 4 : 4096;
+  const size_t lds = (size_t)nv * K * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define CA_GEMV_LAUNCH(NV)                                                                                     \
+  hipLaunchKernelGGL(ca_gemv_kernel<NV>, dim3(grid), dim3(256), lds, s, x, ldx, (const bf16 *)W, (const bf16 *)bias, \
+                     out, ldo, N, K, silu_input, accumulate)
+  switch (nv) {
+    case 1: CA_GEMV_LAUNCH(1); break;
+    case 2: CA_GEMV_LAUNCH(2); break;
+    case 3: CA_GEMV_LAUNCH(3); break;
+    default: CA_GEMV_LAUNCH(4); break;
+  }
+#undef CA_GEMV_LAUNCH
+  return check_launch("ca_gemv_bf16");
+}
+
+extern "C" int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const void *con_vec, int32_t ldc, int32_t L,
+                                      int32_t C, int32_t dim, float *logits, ca_stream_t stream) {
+  if (!img_vec || !con_vec || !logits || L < 1 || C < 1 || dim < 8 || dim % 8 || dim > 4096 || ldi % 8 || ldc % 8 ||
+      ldi < dim || ldc < dim || (((uintptr_t)img_vec | (uintptr_t)con_vec) & 15)) {
+    ca_set_error("ca_heatmap_logits_bf16: bad arguments (L=%d C=%d dim=%d ldi=%d ldc=%d)", L, C, dim, ldi, ldc);
+    return CA_ERR_ARG;
+  }
+  const int grid = (L + 3) / 4 < 2048 ? (L + 3) / 4 : 2048;
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    hipLaunchKernelGGL(ca_heatmap_logits_kernel<4>, dim3(grid), dim3(256), (size_t)4 * dim * 2, (hipStream_t)stream,
+                       (const bf16 *)img_vec, ldi, (const bf16 *)con_vec, ldc, L, C, c0, dim, logits);
+    const int rc = check_launch("ca_heatmap_logits_bf16");
+    if (rc) return rc;
+  }
+  return CA_OK;
+}
+
+extern "C" int ca_heatmap_softmax_accumulate(const float *logits, int32_t C, int32_t L, float weight, float *acc,
+                                             ca_stream_t stream) {
+  if (!logits || !acc || C < 1 || L < 1) {
+    ca_set_error("ca_heatmap_softmax_accumulate: bad arguments (C=%d L=%d)", C, L);
+    return CA_ERR_ARG;
+  }
+  hipLaunchKernelGGL(ca_heatmap_softmax_kernel, dim3((L + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, C, L,
+                     weight, acc);
+  return check_launch("ca_heatmap_softmax_accumulate");
+}
+
+extern "C" int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream) {
+  if (!x || !y || n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) {
+    ca_set_error("ca_axpy_bf16: bad arguments (n=%lld)", (long long)n);
+    return CA_ERR_ARG;
+  }
+  const long blocks = (n + 2047) / 2048;
+  hipLaunchKernelGGL(ca_axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16 *)x,
+                     (const bf16 *)y, a, (long)n);
+  return check_launch("ca_axpy_bf16");
+}

@@ -1,0 +1,193 @@
+"""Tensor-level wrappers over the C ABI (include/conceptattn.h).
+
+PyTorch is used only for device memory and the stream; every operator below runs a hand-written
+gfx950 kernel from libconceptattn.so.  Arguments are validated here for dtype/device and in the
+library for shapes/alignment (ValueError on a rejected argument, nothing is launched).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA(HIP) tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+@dataclass
+class Gemm:
+    """One problem of a grouped GEMM launch: out = epi(a @ w.T + bias)."""
+    a: torch.Tensor                      # [M,K] bf16 (row stride free)
+    w: torch.Tensor                      # [N,K] bf16
+    bias: Optional[torch.Tensor]         # [N] bf16
+    out: torch.Tensor                    # [M,N] bf16 (row stride free)
+    epilogue: int = L.EPI_BIAS
+    resid: Optional[torch.Tensor] = None  # [M,N] bf16, may be `out`
+    gate: Optional[torch.Tensor] = None   # [N] fp32
+    gate2: Optional[torch.Tensor] = None  # [N] fp32 for rows >= gate_rows
+    gate_rows: Optional[int] = None
+    out2: Optional[torch.Tensor] = None   # SPLIT_GELU second output [M,N-n_split]
+    n_split: int = 0
+
+
+def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
+    lib = L.load()
+    arr = (L.GemmProblem * len(problems))()
+    for i, g in enumerate(problems):
+        a, w, out = _chk(g.a, torch.bfloat16, "a"), _chk(g.w, torch.bfloat16, "w"), _chk(g.out, torch.bfloat16, "out")
+        if a.dim() != 2 or w.dim() != 2 or out.dim() != 2 or a.shape[1] != w.shape[1] or a.shape[0] != out.shape[0]:
+            raise ValueError(f"gemm[{i}]: shape mismatch a{tuple(a.shape)} w{tuple(w.shape)} out{tuple(out.shape)}")
+        p = arr[i]
+        p.A, p.W, p.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+        p.bias = _ptr(None if g.bias is None else _chk(g.bias, torch.bfloat16, "bias"))
+        p.M, p.N, p.K = a.shape[0], w.shape[0], a.shape[1]
+        p.lda, p.ldw, p.ldc = a.stride(0), w.stride(0), out.stride(0)
+        p.epilogue = g.epilogue
+        p.gate_rows = p.M if g.gate_rows is None else g.gate_rows
+        if g.epilogue == L.EPI_GATE_RESIDUAL:
+            if g.resid is None or g.gate is None:
+                raise ValueError(f"gemm[{i}]: GATE_RESIDUAL needs resid and gate")
+            p.resid, p.ldr = _chk(g.resid, torch.bfloat16, "resid").data_ptr(), g.resid.stride(0)
+            p.gate = _chk(g.gate, torch.float32, "gate").data_ptr()
+            p.gate2 = _ptr(None if g.gate2 is None else _chk(g.gate2, torch.float32, "gate2"))
+        elif g.epilogue == L.EPI_SPLIT_GELU:
+            if g.out2 is None:
+                raise ValueError(f"gemm[{i}]: SPLIT_GELU needs out2")
+            p.out2, p.ld2, p.n_split = _chk(g.out2, torch.bfloat16, "out2").data_ptr(), g.out2.stride(0), g.n_split
+    L.check(lib.ca_gemm_bf16(arr, len(problems), tile, _stream()), "ca_gemm_bf16")
+
+
+def linear(a, w, bias, out=None, epilogue=L.EPI_BIAS, tile=L.TILE_AUTO, **kw):
+    if out is None:
+        out = torch.empty(a.shape[0], w.shape[0], device=a.device, dtype=torch.bfloat16)
+    gemm([Gemm(a, w, bias, out, epilogue, **kw)], tile)
+    return out
+
+
+@dataclass
+class Attn:
+    """out = softmax(q k^T * scale) v per head; keys/values = rows of (k0,v0) then rows of (k1,v1).
+    q/k/v are 2-D views [rows, num_heads*128] (row stride free), head h at columns h*128.."""
+    q: torch.Tensor
+    out: torch.Tensor
+    k0: torch.Tensor
+    v0: torch.Tensor
+    k1: Optional[torch.Tensor] = None
+    v1: Optional[torch.Tensor] = None
+
+
+def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] = None) -> None:
+    lib = L.load()
+    arr = (L.AttnProblem * len(problems))()
+    for i, a in enumerate(problems):
+        for n in ("q", "out", "k0", "v0"):
+            _chk(getattr(a, n), torch.bfloat16, n)
+        p = arr[i]
+        p.q, p.out, p.k0, p.v0 = a.q.data_ptr(), a.out.data_ptr(), a.k0.data_ptr(), a.v0.data_ptr()
+        p.nq, p.n0 = a.q.shape[0], a.k0.shape[0]
+        p.ldq, p.ldo, p.ldkv = a.q.stride(0), a.out.stride(0), a.k0.stride(0)
+        if a.v0.stride(0) != p.ldkv or a.v0.shape[0] != p.n0 or a.out.shape[0] != p.nq:
+            raise ValueError(f"attention[{i}]: k0/v0/out row mismatch")
+        if a.k1 is not None and a.k1.shape[0] > 0:
+            _chk(a.k1, torch.bfloat16, "k1"), _chk(a.v1, torch.bfloat16, "v1")
+            if a.k1.stride(0) != p.ldkv or a.v1.stride(0) != p.ldkv or a.v1.shape[0] != a.k1.shape[0]:
+                raise ValueError(f"attention[{i}]: both key/value segments must share one row stride")
+            p.k1, p.v1, p.n1 = a.k1.data_ptr(), a.v1.data_ptr(), a.k1.shape[0]
+    if scale is None:
+        scale = 1.0 / math.sqrt(128.0)
+    L.check(lib.ca_attn_fwd_bf16(arr, len(problems), num_heads, scale, _stream()), "ca_attn_fwd_bf16")
+
+
+def ln_modulate(x, out, segments, eps: float = 1e-6) -> None:
+    """segments: [(row_end, shift fp32[H], scale fp32[H]), ...] covering all rows of x."""
+    lib = L.load()
+    _chk(x, torch.bfloat16, "x"), _chk(out, torch.bfloat16, "out")
+    if len(segments) > L.MAX_SEGMENTS:
+        raise ValueError("ln_modulate: too many segments")
+    arr = (L.ModSegment * len(segments))()
+    for i, (row_end, shift, scale) in enumerate(segments):
+        arr[i].row_end = row_end
+        arr[i].shift = _chk(shift, torch.float32, "shift").data_ptr()
+        arr[i].scale = _chk(scale, torch.float32, "scale").data_ptr()
+    L.check(lib.ca_ln_modulate_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+                                    arr, len(segments), eps, _stream()), "ca_ln_modulate_bf16")
+
+
+def qknorm_rope(qkv, num_heads, segments, rope_cos_sin, q_prerope=None) -> None:
+    """In place on the q,k thirds of qkv [M, 3*num_heads*128].
+    segments: [(row_end, q_scale bf16[128], k_scale bf16[128])]; rope_cos_sin fp32 [M,64,2]."""
+    lib = L.load()
+    _chk(qkv, torch.bfloat16, "qkv"), _chk(rope_cos_sin, torch.float32, "rope_cos_sin")
+    M = qkv.shape[0]
+    if tuple(rope_cos_sin.shape) != (M, 64, 2) or not rope_cos_sin.is_contiguous():
+        raise ValueError(f"qknorm_rope: rope table must be contiguous [M,64,2], got {tuple(rope_cos_sin.shape)}")
+    arr = (L.NormSegment * len(segments))()
+    for i, (row_end, qs, ks) in enumerate(segments):
+        arr[i].row_end = row_end
+        arr[i].q_scale = _chk(qs, torch.bfloat16, "q_scale").data_ptr()
+        arr[i].k_scale = _chk(ks, torch.bfloat16, "k_scale").data_ptr()
+    pp, ldp = (None, 0) if q_prerope is None else (_chk(q_prerope, torch.bfloat16, "q_prerope").data_ptr(),
+                                                   q_prerope.stride(0))
+    L.check(lib.ca_qknorm_rope_bf16(qkv.data_ptr(), qkv.stride(0), M, num_heads, arr, len(segments),
+                                    rope_cos_sin.data_ptr(), pp, ldp, _stream()), "ca_qknorm_rope_bf16")
+
+
+def gemv(x, w, bias, out, silu_input=False, accumulate=False) -> None:
+    """out[v,:] (+)= f(x[v,:]) @ w.T + bias; x fp32 [nv,K] (nv<=4), w bf16 [N,K], out fp32 [nv,N]."""
+    lib = L.load()
+    _chk(x, torch.float32, "x"), _chk(w, torch.bfloat16, "w"), _chk(out, torch.float32, "out")
+    if not w.is_contiguous():
+        raise ValueError("gemv: w must be contiguous")
+    b = _ptr(None if bias is None else _chk(bias, torch.bfloat16, "bias"))
+    L.check(lib.ca_gemv_bf16(x.data_ptr(), x.shape[0], x.stride(0), w.data_ptr(), b, out.data_ptr(), out.stride(0),
+                             w.shape[0], w.shape[1], int(silu_input), int(accumulate), _stream()), "ca_gemv_bf16")
+
+
+def heatmap_logits(img_vec, con_vec, logits) -> None:
+    """logits[c,p] = <img_vec[p,:], con_vec[c,:]>; bf16 [L,dim], [C,dim] -> fp32 [C,L]."""
+    lib = L.load()
+    _chk(img_vec, torch.bfloat16, "img_vec"), _chk(con_vec, torch.bfloat16, "con_vec")
+    _chk(logits, torch.float32, "logits")
+    Lp, dim, Cc = img_vec.shape[0], img_vec.shape[1], con_vec.shape[0]
+    if tuple(logits.shape) != (Cc, Lp) or not logits.is_contiguous() or con_vec.shape[1] != dim:
+        raise ValueError("heatmap_logits: shape mismatch")
+    L.check(lib.ca_heatmap_logits_bf16(img_vec.data_ptr(), img_vec.stride(0), con_vec.data_ptr(), con_vec.stride(0),
+                                       Lp, Cc, dim, logits.data_ptr(), _stream()), "ca_heatmap_logits_bf16")
+
+
+def heatmap_softmax_accumulate(logits, acc, weight: float) -> None:
+    lib = L.load()
+    _chk(logits, torch.float32, "logits"), _chk(acc, torch.float32, "acc")
+    if logits.shape != acc.shape or not logits.is_contiguous() or not acc.is_contiguous():
+        raise ValueError("heatmap_softmax_accumulate: logits/acc must be contiguous [C,L]")
+    L.check(lib.ca_heatmap_softmax_accumulate(logits.data_ptr(), logits.shape[0], logits.shape[1], weight,
+                                              acc.data_ptr(), _stream()), "ca_heatmap_softmax_accumulate")
+
+
+def axpy(x, y, a: float) -> None:
+    """x += a*y (bf16, fp32 math)."""
+    lib = L.load()
+    _chk(x, torch.bfloat16, "x"), _chk(y, torch.bfloat16, "y")
+    if not (x.is_contiguous() and y.is_contiguous()) or x.numel() != y.numel():
+        raise ValueError("axpy: x,y must be contiguous with equal sizes")
+    L.check(lib.ca_axpy_bf16(x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream()), "ca_axpy_bf16")

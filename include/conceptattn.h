@@ -1,0 +1,173 @@
+/*
+ * conceptattn.h -- C ABI of libconceptattn.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * ConceptAttention inference hot path.
+ *
+ * The reference (manuragkhullar/ConceptAttention) is pure PyTorch and has no FFI; what this
+ * library replaces are the PyTorch op sequences on the path.  Each
+ * entry point cites the reference lines (relative to the reference root) whose arithmetic it
+ * implements.  The reference-side binding a maintainer would add is the ctypes stub shown in
+ * INTEGRATION.md; conceptattention_amd/_lib.py is that stub.
+ *
+ * Contract (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer borrowed from the caller (PyTorch
+ *     tensors); the library never allocates, frees or retains device memory;
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (a void* here) and does
+ *     no host synchronisation, so calls may be captured into a hipGraph;
+ *   - returns 0 on success, a negative CA_ERR_* code on a rejected argument (nothing is
+ *     launched in that case); ca_last_error() gives a thread-local message;
+ *   - activations and weights are bf16 row-major; modulation vectors, RoPE tables, logits and
+ *     heat-map accumulators are fp32; matrix products accumulate in fp32 (MFMA).
+ *   - head_dim is fixed at 128 (Flux geometry: concept_attention/flux/src/flux/util.py:34-47).
+ */
+#ifndef CONCEPTATTN_H
+#define CONCEPTATTN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CA_VERSION 100 /* 0.1.0 */
+
+#define CA_OK 0
+#define CA_ERR_ARG (-1)    /* bad shape / null pointer / misalignment */
+#define CA_ERR_LAUNCH (-2) /* hip launch failure */
+#define CA_ERR_ARCH (-3)   /* device is not gfx950 */
+
+typedef void *ca_stream_t; /* hipStream_t */
+
+int ca_version(void);
+const char *ca_last_error(void);
+/* 0 if the current device is gfx950, CA_ERR_ARCH otherwise. */
+int ca_check_device(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped GEMM with fused epilogue:  out[m,n] = epi( sum_k A[m,k] * W[n,k] + bias[n] )
+ * Replaces nn.Linear on the path: qkv / proj / mlp of ModifiedDoubleStreamBlock
+ * (concept_attention/modified_double_stream_block.py:90,96,102,194-202), linear1 / linear2 of
+ * ModifiedSingleStreamBlock (concept_attention/modified_single_stream_block.py:49-54), img_in /
+ * txt_in / final_layer.linear (concept_attention/modified_flux_dit.py:98,105,120,159).
+ * Up to CA_GEMM_MAX_PROBLEMS problems share one launch (image stream + text/concept stream of a
+ * double block), so the grid fills all 256 CUs.
+ * Requirements: K % 64 == 0, N % tile_n == 0, lda/ldw/ldc/ldr/ld2 % 8 == 0, 16-byte aligned
+ * pointers.  M is arbitrary (rows are masked).
+ */
+enum {
+  CA_EPI_BIAS = 0,          /* out = acc + bias */
+  CA_EPI_GELU_TANH = 1,     /* out = gelu_tanh(acc + bias)          (mlp.0, :196)          */
+  CA_EPI_GATE_RESIDUAL = 2, /* out = resid + gate[n]*(acc + bias)   (:194-202)             */
+  CA_EPI_SPLIT_GELU = 3     /* n <  n_split: out  = acc + bias                             */
+                            /* n >= n_split: out2 = gelu_tanh(acc+bias), column n-n_split  */
+                            /* (single block linear1 -> qkv | mlp, single_stream_block:49) */
+};
+
+enum { CA_TILE_AUTO = 0, CA_TILE_256x256 = 1, CA_TILE_256x192 = 2, CA_TILE_256x128 = 3, CA_TILE_256x64 = 4 };
+
+#define CA_GEMM_MAX_PROBLEMS 2
+
+typedef struct {
+  const void *A;     /* bf16 [M,K], row stride lda (elements) */
+  const void *W;     /* bf16 [N,K], row stride ldw: nn.Linear weight (out,in) */
+  const void *bias;  /* bf16 [N] or NULL */
+  void *out;         /* bf16 [M,N] (or [M,n_split] for SPLIT_GELU), row stride ldc */
+  const void *resid; /* bf16 [M,N], row stride ldr; GATE_RESIDUAL only; may alias out */
+  const float *gate; /* fp32 [N]; GATE_RESIDUAL: gate for rows <  gate_rows */
+  const float *gate2;/* fp32 [N]; GATE_RESIDUAL: gate for rows >= gate_rows (may be NULL if gate_rows >= M) */
+  void *out2;        /* bf16 [M,N-n_split], row stride ld2; SPLIT_GELU only */
+  int32_t M, N, K;
+  int32_t lda, ldw, ldc, ldr, ld2;
+  int32_t n_split;   /* SPLIT_GELU: multiple of the tile width */
+  int32_t gate_rows;
+  int32_t epilogue;  /* CA_EPI_* */
+} ca_gemm_problem;
+
+int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile, ca_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flash attention forward, head_dim 128, no mask:  out = softmax(q k^T * scale) v  per head.
+ * Replaces F.scaled_dot_product_attention at modified_double_stream_block.py:112-116 (text+image
+ * rows) and :162-168 (concept rows; only the C concept query rows are evaluated, which equals
+ * rows [:C] of the reference's (C+L)x(C+L) product), and flux/math.py:6-12 for the single blocks.
+ * q/k/v are read in place from a [rows, >=3*H*128] projection buffer: head h of a row lives at
+ * column h*128 of the pointer given; the output is written head-concatenated ("B H L D -> B L (H D)",
+ * modified_double_stream_block.py:170-176).  The key/value set of a problem is the concatenation
+ * of two row segments (segment 1 may be empty), e.g. [concept rows ; image rows].
+ * Up to 2 problems share one launch (main rows + concept rows).
+ */
+typedef struct {
+  const void *q; /* bf16, row stride ldq */
+  void *out;     /* bf16, row stride ldo */
+  const void *k0, *v0; /* segment 0: n0 rows, row stride ldkv */
+  const void *k1, *v1; /* segment 1: n1 rows, row stride ldkv */
+  int32_t nq, n0, n1;
+  int32_t ldq, ldo, ldkv;
+} ca_attn_problem;
+
+int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
+                     float scale, ca_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm (no affine, eps) followed by adaLN modulation:  out = (1 + scale) * LN(x) + shift
+ * modified_double_stream_block.py:88-89,94-95,100-101,196,199,202; single_stream_block:48;
+ * LastLayer flux/modules/layers.py:250-251.  Row ranges may use different modulation vectors
+ * (concept rows / text rows / image rows): segment i covers rows [row_end[i-1], row_end[i]).
+ */
+#define CA_MAX_SEGMENTS 4
+typedef struct {
+  int32_t row_end;
+  int32_t _pad;
+  const float *shift; /* fp32 [H] */
+  const float *scale; /* fp32 [H] */
+} ca_mod_segment;
+
+int ca_ln_modulate_bf16(const void *x, int32_t ldx, void *out, int32_t ldo, int32_t M, int32_t H,
+                        const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * QK-RMSNorm + RoPE, in place on the q and k thirds of a [M, 3*H*128] projection buffer.
+ * QKNorm: flux/modules/layers.py:63-84 (fp32, eps 1e-6, per-head scale[128]);
+ * apply_rope: flux/math.py:25-30 (interleaved pairs (2i,2i+1)); rope table [M,64,2] fp32 =
+ * (cos,sin) of rope() flux/math.py:15-22 computed by the host in float64.
+ * Optionally stores the normalised, PRE-RoPE q (what the reference captures as
+ * cross_attention_{image,concept}_vectors, modified_double_stream_block.py:189-190) to q_prerope.
+ */
+typedef struct {
+  int32_t row_end;
+  int32_t _pad;
+  const void *q_scale; /* bf16 [128] */
+  const void *k_scale; /* bf16 [128] */
+} ca_norm_segment;
+
+int ca_qknorm_rope_bf16(void *qkv, int32_t ld, int32_t M, int32_t num_heads,
+                        const ca_norm_segment *segs, int32_t n_segs, const float *rope_cos_sin,
+                        void *q_prerope, int32_t ldp, ca_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small-batch matrix-vector products (weight streaming, HBM-bound):
+ *   out[v,n] (+)= sum_k f(x[v,k]) * W[n,k] + bias[n],  v < nv <= 4,  f = SiLU or identity.
+ * Modulation (flux/modules/layers.py:113-126), MLPEmbedder (:52-60), LastLayer.adaLN (:246,249).
+ */
+int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void *W, const void *bias, float *out,
+                 int32_t ldo, int32_t N, int32_t K, int32_t silu_input, int32_t accumulate,
+                 ca_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Concept heat maps, one (timestep, layer) at a time (compute_heatmaps_from_vectors,
+ * concept_attention/concept_attention_pipeline.py:29-91, softmax branch):
+ *   logits[c,p] = <img_vec[p,:], con_vec[c,:]>                                   (:57-61)
+ *   acc[c,p]   += weight * softmax_c(logits[:,p])        (weight = 1/(|timesteps|*|layers|), :64-82)
+ * fp32 accumulation (the reference does this in bf16; see DESIGN.md "tolerance").
+ */
+int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const void *con_vec, int32_t ldc,
+                           int32_t L, int32_t C, int32_t dim, float *logits, ca_stream_t stream);
+int ca_heatmap_softmax_accumulate(const float *logits, int32_t C, int32_t L, float weight, float *acc,
+                                  ca_stream_t stream);
+
+/* Euler step of denoise(): x = x + a*y  (flux/sampling.py:141), bf16 in/out, fp32 math. */
+int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONCEPTATTN_H */

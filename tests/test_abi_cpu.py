@@ -1,0 +1,59 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/conceptattn.h declares, and rejects bad arguments without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as entry
+from conceptattention_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    entry.build()
+    return L.load()
+
+
+def test_header_symbols_all_exported(lib):
+    text = open(os.path.join(ROOT, "include", "conceptattn.h")).read()
+    declared = set(re.findall(r"\b(ca_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_version_and_error_string(lib):
+    assert lib.ca_version() == L.CA_VERSION
+    assert isinstance(lib.ca_last_error(), bytes)
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler sees (LP64): pointers 8, int32 4, no implicit padding inside
+    assert ctypes.sizeof(L.GemmProblem) == 8 * 8 + 11 * 4 + 4
+    assert ctypes.sizeof(L.AttnProblem) == 6 * 8 + 6 * 4
+    assert ctypes.sizeof(L.ModSegment) == 24 and ctypes.sizeof(L.NormSegment) == 24
+
+
+def test_argument_rejection_needs_no_gpu(lib):
+    assert lib.ca_gemm_bf16(None, 1, 0, None) == -1
+    assert b"n_problems" in lib.ca_last_error() or b"ca_gemm" in lib.ca_last_error()
+    p = (L.GemmProblem * 1)()
+    p[0].M, p[0].N, p[0].K = 16, 256, 100  # K % 64 != 0, null pointers
+    assert lib.ca_gemm_bf16(p, 1, L.TILE_256x256, None) == -1
+    a = (L.AttnProblem * 1)()
+    assert lib.ca_attn_fwd_bf16(a, 1, 24, 0.1, None) == -1
+    assert lib.ca_attn_fwd_bf16(a, 3, 24, 0.1, None) == -1
+    assert lib.ca_axpy_bf16(None, None, 1.0, 0, None) == -1
+    assert lib.ca_gemv_bf16(None, 5, 0, None, None, None, 0, 0, 0, 0, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.ConceptAttnError):
+        L.load()

@@ -1,0 +1,246 @@
+"""Each gfx950 kernel (called through the C ABI) against an fp32 reference of the same op on the
+same bf16-representable inputs.  Tolerances are stated per test: outputs are bf16 (8-bit mantissa,
+relative quantum 2^-8 = 3.9e-3), accumulation is fp32."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conceptattention_amd import _lib as L  # noqa: E402
+from conceptattention_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).bfloat16()
+
+
+def close(out, ref, atol, rtol=8e-3):
+    """|out-ref| <= atol + rtol*|ref| elementwise (rtol = 2 bf16 ulps)."""
+    out, ref = out.float(), ref.float()
+    err = (out - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    assert not bad.any(), f"max err {err.max().item():.4g} (ref max {ref.abs().max().item():.4g}), {bad.sum().item()} bad"
+
+
+def test_device_is_gfx950():
+    assert L.load().ca_check_device() == 0, L.load().ca_last_error()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric W catches a transposed / permuted C layout exactly."""
+    K = N = 256
+    a = torch.eye(256, K, device=DEV).bfloat16()
+    w = (torch.arange(N, device=DEV)[:, None] * 3 + torch.arange(K, device=DEV)[None, :] * 5) % 251
+    w = (w.float() - 125).bfloat16()  # integers < 256: exact in bf16
+    for tile in (L.TILE_256x256, L.TILE_256x192 if N % 192 == 0 else L.TILE_256x128, L.TILE_256x128, L.TILE_256x64):
+        out = ops.linear(a, w, None, tile=tile)
+        assert torch.equal(out.float(), w.float().t().contiguous()), f"tile {tile}"
+
+
+@pytest.mark.parametrize("tile,N", [(L.TILE_256x256, 512), (L.TILE_256x192, 384), (L.TILE_256x128, 384),
+                                    (L.TILE_256x64, 64), (L.TILE_AUTO, 768)])
+@pytest.mark.parametrize("M", [4, 260, 513])
+def test_gemm_bias_tails(tile, N, M):
+    K = 192
+    a, w, b = rnd(M, K), rnd(N, K, scale=0.1), rnd(N)
+    out = ops.linear(a, w, b, tile=tile)
+    ref = a.float() @ w.float().t() + b.float()
+    close(out, ref, atol=2e-2)
+
+
+def test_gemm_epilogues_and_strides():
+    M, N, K = 300, 512, 320
+    big = rnd(M, K + 64)
+    a = big[:, 32:32 + K]  # row stride K+64, 16-byte aligned offset
+    w, b = rnd(N, K, scale=0.1), rnd(N)
+    lin = a.float() @ w.float().t() + b.float()
+    out = ops.linear(a, w, b, epilogue=L.EPI_GELU_TANH)
+    close(out, torch.nn.functional.gelu(lin, approximate="tanh"), atol=2e-2)
+    # gate * x + residual with two gate vectors (rows < 7 use gate, the rest gate2), in place
+    resid = rnd(M, N)
+    g1, g2 = rnd(N).float(), rnd(N, seed=5).float()
+    ref = resid.float() + torch.where(torch.arange(M, device=DEV)[:, None] < 7, g1[None], g2[None]) * lin
+    x = resid.clone()
+    ops.gemm([ops.Gemm(a, w, b, x, L.EPI_GATE_RESIDUAL, resid=x, gate=g1, gate2=g2, gate_rows=7)])
+    close(x, ref, atol=3e-2)
+    # split: first 256 columns plain, remaining 256 GELU into a strided destination
+    o1 = torch.zeros(M, 256, device=DEV, dtype=torch.bfloat16)
+    cat = torch.zeros(M, 128 + 256, device=DEV, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(a, w, b, o1, L.EPI_SPLIT_GELU, out2=cat[:, 128:], n_split=256)])
+    close(o1, lin[:, :256], atol=2e-2)
+    close(cat[:, 128:], torch.nn.functional.gelu(lin[:, 256:], approximate="tanh"), atol=2e-2)
+    assert cat[:, :128].abs().max() == 0
+
+
+def test_gemm_grouped_two_problems():
+    a0, w0, b0 = rnd(700, 256), rnd(768, 256, scale=0.1), rnd(768)
+    a1, w1, b1 = rnd(260, 128), rnd(512, 128, scale=0.1), rnd(512)
+    o0 = torch.empty(700, 768, device=DEV, dtype=torch.bfloat16)
+    o1 = torch.empty(260, 512, device=DEV, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(a0, w0, b0, o0), ops.Gemm(a1, w1, b1, o1, L.EPI_GELU_TANH)])
+    close(o0, a0.float() @ w0.float().t() + b0.float(), atol=2e-2)
+    close(o1, torch.nn.functional.gelu(a1.float() @ w1.float().t() + b1.float(), approximate="tanh"), atol=2e-2)
+
+
+def test_gemm_rejects_bad_arguments():
+    a, w = rnd(16, 100), rnd(256, 100)
+    with pytest.raises(ValueError):
+        ops.linear(a, w, None)  # K % 64 != 0
+    with pytest.raises(ValueError):
+        ops.linear(rnd(16, 128), rnd(100, 128), None)  # N not a multiple of any tile width
+
+
+def test_gemm_full_size_flux_shapes():
+    """M=4352 (T+L), the single-block linear1 split: N=21504 -> qkv 9216 | mlp 12288, K=3072."""
+    M, K = 4352, 3072
+    a, w, b = rnd(M, K), rnd(21504, K, scale=0.02), rnd(21504)
+    qkv = torch.empty(M, 9216, device=DEV, dtype=torch.bfloat16)
+    cat = torch.empty(M, 15360, device=DEV, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(a, w, b, qkv, L.EPI_SPLIT_GELU, out2=cat[:, 3072:], n_split=9216)])
+    ref = a.float() @ w.float().t() + b.float()
+    close(qkv, ref[:, :9216], atol=3e-2)
+    close(cat[:, 3072:], torch.nn.functional.gelu(ref[:, 9216:], approximate="tanh"), atol=3e-2)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, nh):
+    """fp32 softmax(q k^T / sqrt(128)) v on [rows, nh*128] views."""
+    qh = q.float().view(q.shape[0], nh, 128).transpose(0, 1)
+    kh = k.float().view(k.shape[0], nh, 128).transpose(0, 1)
+    vh = v.float().view(v.shape[0], nh, 128).transpose(0, 1)
+    w = torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(128), dim=-1)
+    return (w @ vh).transpose(0, 1).reshape(q.shape[0], nh * 128)
+
+
+@pytest.mark.parametrize("nq,nk", [(300, 200), (32, 64), (7, 1), (513, 1000)])
+def test_attention_ragged(nq, nk):
+    nh = 3
+    qkv_q = rnd(nq, 3 * nh * 128)
+    qkv_k = rnd(nk, 3 * nh * 128, seed=1)
+    q, k, v = qkv_q[:, :nh * 128], qkv_k[:, nh * 128:2 * nh * 128], qkv_k[:, 2 * nh * 128:]
+    out = torch.zeros(nq, nh * 128, device=DEV, dtype=torch.bfloat16)
+    ops.attention([ops.Attn(q, out, k, v)], nh)
+    close(out, attn_ref(q, k, v, nh), atol=1e-2)
+
+
+def test_attention_two_segments_and_two_problems():
+    """Concept rows attend to [concept keys ; image keys]; main rows to [text ; image] in one launch."""
+    nh, C, T, Limg = 2, 5, 40, 333
+    buf = rnd(C + T + Limg, 3 * nh * 128, scale=1.5)
+    H = nh * 128
+    q, k, v = buf[:, :H], buf[:, H:2 * H], buf[:, 2 * H:]
+    out = torch.zeros(C + T + Limg, H, device=DEV, dtype=torch.bfloat16)
+    main = ops.Attn(q[C:], out[C:], k[C:], v[C:])
+    con = ops.Attn(q[:C], out[:C], k[:C], v[:C], k[C + T:], v[C + T:])
+    ops.attention([main, con], nh)
+    close(out[C:], attn_ref(q[C:], k[C:], v[C:], nh), atol=1e-2)
+    kc, vc = torch.cat((k[:C], k[C + T:])), torch.cat((v[:C], v[C + T:]))
+    close(out[:C], attn_ref(q[:C], kc, vc, nh), atol=1e-2)
+
+
+def test_attention_online_softmax_rescale_spike():
+    """A key far down the sequence dominates one query row: the running max must jump at that tile."""
+    nh, nq, nk = 1, 64, 640
+    q, k, v = rnd(nq, 128), rnd(nk, 128, seed=3), rnd(nk, 128, seed=4)
+    k[500] = (q[17].float() * 4).bfloat16()  # logit ~ 4*|q|^2/sqrt(128) >> others
+    out = torch.zeros(nq, 128, device=DEV, dtype=torch.bfloat16)
+    ops.attention([ops.Attn(q, out, k, v)], nh)
+    close(out, attn_ref(q, k, v, nh), atol=1e-2)
+
+
+def test_attention_full_size():
+    """24 heads, 4352 rows (T=256 + L=4096) read in place from a [rows, 9216] projection buffer."""
+    nh, n = 24, 4352
+    buf = rnd(n, 9216)
+    q, k, v = buf[:, :3072], buf[:, 3072:6144], buf[:, 6144:]
+    out = torch.zeros(n, 3072, device=DEV, dtype=torch.bfloat16)
+    ops.attention([ops.Attn(q, out, k, v)], nh)
+    ref = torch.cat([attn_ref(q[i:i + 1088], k, v, nh) for i in range(0, n, 1088)])
+    close(out, ref, atol=5e-3)
+
+
+# ------------------------------------------------------------------------------------------ row kernels
+def test_ln_modulate_segments():
+    M, H = 70, 3072
+    x = rnd(M, H, scale=2.0)
+    sh = [torch.randn(H, device=DEV) for _ in range(3)]
+    sc = [torch.randn(H, device=DEV) * 0.3 for _ in range(3)]
+    out = torch.empty_like(x)
+    ops.ln_modulate(x, out, [(4, sh[0], sc[0]), (36, sh[1], sc[1]), (M, sh[2], sc[2])])
+    ln = torch.nn.functional.layer_norm(x.float(), (H,), eps=1e-6)
+    seg = torch.tensor([0] * 4 + [1] * 32 + [2] * (M - 36), device=DEV)
+    ref = (1 + torch.stack(sc)[seg]) * ln + torch.stack(sh)[seg]
+    close(out, ref, atol=1e-2)
+    # small hidden size (tiny test geometry)
+    x2 = rnd(9, 256)
+    o2 = torch.empty_like(x2)
+    ops.ln_modulate(x2, o2, [(9, sh[0][:256].contiguous(), sc[0][:256].contiguous())])
+    close(o2, (1 + sc[0][:256]) * torch.nn.functional.layer_norm(x2.float(), (256,), eps=1e-6) + sh[0][:256], atol=1e-2)
+
+
+def test_qknorm_rope_matches_oracle():
+    from oracle import flux_oracle as O
+    nh, M, C = 2, 50, 3
+    qkv = rnd(M, 3 * nh * 128, scale=2.0)
+    orig = qkv.clone()
+    ids = torch.zeros(M, 3)
+    ids[C:, 1] = torch.arange(M - C) // 8
+    ids[C:, 2] = torch.arange(M - C) % 8
+    cos, sin = O.rope_cos_sin(ids, (16, 56, 56), 10000)
+    table = torch.stack((cos, sin), -1).contiguous().to(DEV)
+    qs = [(0.5 + torch.rand(128)).bfloat16().to(DEV) for _ in range(4)]
+    pre = torch.zeros(M, nh * 128, device=DEV, dtype=torch.bfloat16)
+    ops.qknorm_rope(qkv, nh, [(10, qs[0], qs[1]), (M, qs[2], qs[3])], table, q_prerope=pre)
+    x = orig.float().cpu().view(M, 3, nh, 128)
+    for which in (0, 1):
+        sc = torch.stack([qs[which].float().cpu()] * 10 + [qs[2 + which].float().cpu()] * (M - 10))  # [M,128]
+        normed = O.rms_norm(x[:, which], sc[:, None, :])
+        if which == 0:
+            close(pre.cpu(), normed.reshape(M, -1), atol=1e-2)
+        roped = O.apply_rope(normed.permute(1, 0, 2)[None], cos, sin)[0].permute(1, 0, 2)
+        close(qkv.cpu().view(M, 3, nh, 128)[:, which], roped, atol=1e-2)
+    assert torch.equal(qkv.view(M, 3, nh, 128)[:, 2], orig.view(M, 3, nh, 128)[:, 2])  # v untouched
+
+
+@pytest.mark.parametrize("nv,K,N", [(1, 256, 3072), (2, 3072, 18432), (3, 768, 100), (4, 4096, 64)])
+def test_gemv(nv, K, N):
+    x = torch.randn(nv, K, device=DEV)
+    w, b = rnd(N, K, scale=0.05), rnd(N)
+    out = torch.zeros(nv, N, device=DEV)
+    ops.gemv(x, w, b, out, silu_input=True)
+    ref = torch.nn.functional.silu(x) @ w.float().t() + b.float()
+    assert (out - ref).abs().max() < 2e-3
+    ops.gemv(x, w, None, out, silu_input=False, accumulate=True)
+    assert (out - (ref + x @ w.float().t())).abs().max() < 4e-3
+
+
+@pytest.mark.parametrize("C", [1, 4, 6])
+def test_heatmap_logits_softmax_accumulate(C):
+    Lp, dim = 4096, 3072
+    img, con = rnd(Lp, dim), rnd(C, dim, scale=0.05)
+    logits = torch.empty(C, Lp, device=DEV)
+    ops.heatmap_logits(img, con, logits)
+    ref = con.float() @ img.float().t()
+    assert (logits - ref).abs().max() < 1e-3 * max(1.0, ref.abs().max().item())
+    acc = torch.full((C, Lp), 0.25, device=DEV)
+    ops.heatmap_softmax_accumulate(logits, acc, 0.5)
+    assert (acc - (0.25 + 0.5 * torch.softmax(ref, dim=0))).abs().max() < 1e-4
+
+
+def test_axpy():
+    x, y = rnd(4096, 64), rnd(4096, 64, seed=9)
+    ref = x.float() - 0.25 * y.float()
+    ops.axpy(x, y, -0.25)
+    close(x, ref, atol=1e-3)
+    x2, y2 = rnd(1001), rnd(1001, seed=2)
+    x2 = x2[:1000].clone()  # 16-byte aligned, not a multiple of 8 elements
+    ref2 = x2.float() + 2 * y2[:1000].float()
+    ops.axpy(x2, y2[:1000].clone(), 2.0)
+    close(x2, ref2, atol=1e-3)

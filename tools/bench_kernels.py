@@ -1,0 +1,94 @@
+"""Micro-benchmarks of the individual gfx950 kernels at the Flux shapes (development aid;
+bench.py is the judged benchmark).  Prints TFLOP/s or GB/s per kernel on random data."""
+import math
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from conceptattention_amd import _lib as L
+from conceptattention_amd import ops
+
+dev = "cuda"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).bfloat16()
+
+
+def bench_gemm(M, N, K, tile=L.TILE_AUTO, epi=L.EPI_BIAS, name=""):
+    a, w, b = rnd(M, K), rnd(N, K, scale=0.02), rnd(N)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    kw = {}
+    if epi == L.EPI_GATE_RESIDUAL:
+        kw = dict(resid=out, gate=torch.randn(N, device=dev))
+    t = timeit(lambda: ops.gemm([ops.Gemm(a, w, b, out, epi, **kw)], tile))
+    print(f"gemm {name:10s} M={M:5d} N={N:5d} K={K:5d} tile={tile} epi={epi}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
+    return t
+
+
+def bench_attn(n, nh=24, C=0):
+    buf = rnd(n + C, 3 * nh * 128)
+    H = nh * 128
+    q, k, v = buf[:, :H], buf[:, H:2 * H], buf[:, 2 * H:]
+    out = torch.empty(n + C, H, device=dev, dtype=torch.bfloat16)
+    probs = [ops.Attn(q[C:], out[C:], k[C:], v[C:])]
+    if C:
+        probs.append(ops.Attn(q[:C], out[:C], k[:C], v[:C], k[C + 256:], v[C + 256:]))
+    t = timeit(lambda: ops.attention(probs, nh))
+    fl = 4 * n * n * 128 * nh
+    print(f"attn n={n} heads={nh} C={C}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    print(torch.cuda.get_device_name(0))
+    for tile in (L.TILE_256x256, L.TILE_256x192, L.TILE_256x128):
+        bench_gemm(4096, 9216, 3072, tile, name="qkv")
+    for tile in (L.TILE_256x256, L.TILE_256x192, L.TILE_256x128):
+        bench_gemm(4096, 3072, 3072, tile, L.EPI_GATE_RESIDUAL, name="proj")
+    bench_gemm(4096, 12288, 3072, L.TILE_256x256, L.EPI_GELU_TANH, name="mlp0")
+    for tile in (L.TILE_256x256, L.TILE_256x192):
+        bench_gemm(4096, 3072, 12288, tile, L.EPI_GATE_RESIDUAL, name="mlp2")
+    bench_gemm(4352, 21504, 3072, L.TILE_256x256, name="linear1")
+    bench_gemm(4352, 3072, 15360, L.TILE_256x256, L.EPI_GATE_RESIDUAL, name="linear2")
+    bench_gemm(8192, 8192, 8192, L.TILE_256x256, name="8k")
+    bench_gemm(260, 9216, 3072, L.TILE_256x256, name="txt-qkv")
+    bench_attn(4352)
+    bench_attn(4352, C=4)
+    bench_attn(4608)
+    # row kernels
+    x = rnd(4356, 3072)
+    o = torch.empty_like(x)
+    sh, sc = torch.randn(3072, device=dev), torch.randn(3072, device=dev)
+    t = timeit(lambda: ops.ln_modulate(x, o, [(4356, sh, sc)]))
+    print(f"ln_modulate 4356x3072: {t*1e6:.1f} us  {2*x.numel()*2/t/1e9:.0f} GB/s")
+    qkv = rnd(4356, 9216)
+    table = torch.zeros(4356, 64, 2, device=dev)
+    table[..., 0] = 1
+    s128 = torch.ones(128, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda: ops.qknorm_rope(qkv, 24, [(4356, s128, s128)], table))
+    print(f"qknorm_rope 4356x6144: {t*1e6:.1f} us  {2*4356*6144*2/t/1e9:.0f} GB/s")
+    w = rnd(18432 * 8, 3072, scale=0.02)
+    xv = torch.randn(2, 3072, device=dev)
+    ov = torch.empty(2, 18432 * 8, device=dev)
+    t = timeit(lambda: ops.gemv(xv, w, None, ov, silu_input=True))
+    print(f"gemv 2x3072 -> {w.shape[0]}: {t*1e6:.1f} us  {w.numel()*2/t/1e9:.0f} GB/s")
+    img, con = rnd(4096, 3072), rnd(4, 3072)
+    lg = torch.empty(4, 4096, device=dev)
+    acc = torch.zeros(4, 4096, device=dev)
+    t = timeit(lambda: (ops.heatmap_logits(img, con, lg), ops.heatmap_softmax_accumulate(lg, acc, 1.0)))
+    print(f"heatmap 4096x3072 C=4: {t*1e6:.1f} us  {img.numel()*2/t/1e9:.0f} GB/s")
