@@ -29,9 +29,9 @@ class GemmProblem(C.Structure):
 
 class AttnProblem(C.Structure):
     _fields_ = [("q", C.c_void_p), ("out", C.c_void_p), ("k0", C.c_void_p), ("v0", C.c_void_p),
-                ("k1", C.c_void_p), ("v1", C.c_void_p),
+                ("k1", C.c_void_p), ("v1", C.c_void_p), ("out_f32", C.c_void_p),
                 ("nq", C.c_int32), ("n0", C.c_int32), ("n1", C.c_int32),
-                ("ldq", C.c_int32), ("ldo", C.c_int32), ("ldkv", C.c_int32)]
+                ("ldq", C.c_int32), ("ldo", C.c_int32), ("ldkv", C.c_int32), ("ldo32", C.c_int32)]
 
 
 class ModSegment(C.Structure):
@@ -56,9 +56,11 @@ SIGNATURES = {
     "ca_gemv_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ca_heatmap_logits_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                                         C.c_int32, C.c_void_p, C.c_void_p]),
+                                         C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ca_heatmap_softmax_accumulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                                 C.c_void_p]),
+    "ca_timestep_embedding_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                            C.c_void_p]),
     "ca_axpy_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
 }
 

@@ -221,6 +221,15 @@ __global__ __launch_bounds__(512, 2) void ca_attn_kernel(const AttnLaunch L) {
                                      ca_pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
           *(uint2 *)(op + 32 * db + 8 * g) = v;
         }
+      if (P.out_f32) {
+        float *fp = P.out_f32 + (size_t)(qrow0 + ql) * P.ldo32 + head * 128 + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *(f32x4 *)(fp + 32 * db + 8 * g) =
+                f32x4{o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
+      }
     }
   }
 }
@@ -249,8 +258,12 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
       ca_set_error("ca_attn_fwd_bf16[%d]: row strides must be >= num_heads*128 and multiples of 8", i);
       return CA_ERR_ARG;
     }
+    if (p.out_f32 && (p.ldo32 % 4 || p.ldo32 < num_heads * 128)) {
+      ca_set_error("ca_attn_fwd_bf16[%d]: ldo32 must be >= num_heads*128 and a multiple of 4", i);
+      return CA_ERR_ARG;
+    }
     if (((uintptr_t)p.q | (uintptr_t)p.out | (uintptr_t)p.k0 | (uintptr_t)p.v0 | (uintptr_t)p.k1 |
-         (uintptr_t)p.v1) & 15) {
+         (uintptr_t)p.v1 | (uintptr_t)p.out_f32) & 15) {
       ca_set_error("ca_attn_fwd_bf16[%d]: pointers must be 16-byte aligned", i);
       return CA_ERR_ARG;
     }

@@ -192,18 +192,19 @@ __global__ __launch_bounds__(256) void ca_gemv_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// logits[c,p] = <img_vec[p,:], con_vec[c,:]> for CC concepts per pass; one wave per patch
-template <int CC>
+// logits[c,p] = <img_vec[p,:], con_vec[c,:]> for CC concepts per pass; one wave per patch.
+// The concept vectors sit in LDS as fp32 (they are either bf16 or already fp32 in HBM).
+template <int CC, typename CT>
 __global__ __launch_bounds__(256) void ca_heatmap_logits_kernel(const bf16 *__restrict__ img, int ldi,
-                                                                const bf16 *__restrict__ con, int ldc, int L,
+                                                                const CT *__restrict__ con, int ldc, int L,
                                                                 int C, int c0, int dim,
                                                                 float *__restrict__ logits) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16 *cs = (bf16 *)smem_raw;  // [CC][dim]
-  for (int i = threadIdx.x * 8; i < CC * dim; i += 256 * 8) {
+  float *cs = (float *)smem_raw;  // [CC][dim]
+  for (int i = threadIdx.x; i < CC * dim; i += 256) {
     const int c = i / dim, k = i - c * dim;
     const int cr = min(c0 + c, C - 1);
-    *(uint4 *)(cs + i) = *(const uint4 *)(con + (size_t)cr * ldc + k);
+    cs[i] = (float)con[(size_t)cr * ldc + k];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -217,9 +218,12 @@ __global__ __launch_bounds__(256) void ca_heatmap_logits_kernel(const bf16 *__re
       const bf16x8 a = *(const bf16x8 *)(ir + k);
 #pragma unroll
       for (int c = 0; c < CC; ++c) {
-        const bf16x8 b = *(const bf16x8 *)(cs + c * dim + k);
+        const f32x4 b0 = *(const f32x4 *)(cs + c * dim + k), b1 = *(const f32x4 *)(cs + c * dim + k + 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[c] = fmaf((float)a[j], (float)b[j], acc[c]);
+        for (int j = 0; j < 4; ++j) {
+          acc[c] = fmaf((float)a[j], b0[j], acc[c]);
+          acc[c] = fmaf((float)a[4 + j], b1[j], acc[c]);
+        }
       }
     }
 #pragma unroll
@@ -257,6 +261,20 @@ __global__ __launch_bounds__(256) void ca_axpy_kernel(bf16 *__restrict__ x, cons
   } else {
     for (long j = i; j < n; ++j) x[j] = (bf16)fmaf(a, (float)y[j], (float)x[j]);
   }
+}
+
+// sinusoidal timestep embedding: out[v, 0:half] = cos(tf*t[v]*f_i), out[v, half:] = sin(...)
+__global__ __launch_bounds__(256) void ca_timestep_embedding_kernel(const float *__restrict__ t, int nt,
+                                                                    float *__restrict__ out, int dim,
+                                                                    float time_factor, float max_period) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nt * half) return;
+  const int v = i / half, k = i - v * half;
+  const float freq = expf(-logf(max_period) * (float)k / (float)half);
+  const float arg = time_factor * t[v] * freq;
+  out[(size_t)v * dim + k] = cosf(arg);
+  out[(size_t)v * dim + half + k] = sinf(arg);
 }
 
 int check_launch(const char *what) {
@@ -355,17 +373,23 @@ extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void 
   return check_launch("ca_gemv_bf16");
 }
 
-extern "C" int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const void *con_vec, int32_t ldc, int32_t L,
-                                      int32_t C, int32_t dim, float *logits, ca_stream_t stream) {
-  if (!img_vec || !con_vec || !logits || L < 1 || C < 1 || dim < 8 || dim % 8 || dim > 4096 || ldi % 8 || ldc % 8 ||
+extern "C" int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const void *con_vec, int32_t ldc,
+                                      int32_t con_is_f32, int32_t L, int32_t C, int32_t dim, float *logits,
+                                      ca_stream_t stream) {
+  if (!img_vec || !con_vec || !logits || L < 1 || C < 1 || dim < 8 || dim % 8 || dim > 4096 || ldi % 8 ||
       ldi < dim || ldc < dim || (((uintptr_t)img_vec | (uintptr_t)con_vec) & 15)) {
     ca_set_error("ca_heatmap_logits_bf16: bad arguments (L=%d C=%d dim=%d ldi=%d ldc=%d)", L, C, dim, ldi, ldc);
     return CA_ERR_ARG;
   }
   const int grid = (L + 3) / 4 < 2048 ? (L + 3) / 4 : 2048;
+  const size_t lds = (size_t)4 * dim * sizeof(float);
   for (int c0 = 0; c0 < C; c0 += 4) {
-    hipLaunchKernelGGL(ca_heatmap_logits_kernel<4>, dim3(grid), dim3(256), (size_t)4 * dim * 2, (hipStream_t)stream,
-                       (const bf16 *)img_vec, ldi, (const bf16 *)con_vec, ldc, L, C, c0, dim, logits);
+    if (con_is_f32)
+      hipLaunchKernelGGL((ca_heatmap_logits_kernel<4, float>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
+                         (const bf16 *)img_vec, ldi, (const float *)con_vec, ldc, L, C, c0, dim, logits);
+    else
+      hipLaunchKernelGGL((ca_heatmap_logits_kernel<4, bf16>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
+                         (const bf16 *)img_vec, ldi, (const bf16 *)con_vec, ldc, L, C, c0, dim, logits);
     const int rc = check_launch("ca_heatmap_logits_bf16");
     if (rc) return rc;
   }
@@ -392,4 +416,16 @@ extern "C" int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_strea
   hipLaunchKernelGGL(ca_axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16 *)x,
                      (const bf16 *)y, a, (long)n);
   return check_launch("ca_axpy_bf16");
+}
+
+extern "C" int ca_timestep_embedding_f32(const float *t, int32_t nt, float *out, int32_t dim, float time_factor,
+                                         float max_period, ca_stream_t stream) {
+  if (!t || !out || nt < 1 || dim < 2 || dim % 2) {
+    ca_set_error("ca_timestep_embedding_f32: bad arguments (nt=%d dim=%d)", nt, dim);
+    return CA_ERR_ARG;
+  }
+  const int n = nt * (dim / 2);
+  hipLaunchKernelGGL(ca_timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, nt,
+                     out, dim, time_factor, max_period);
+  return check_launch("ca_timestep_embedding_f32");
 }

@@ -1,0 +1,385 @@
+"""HipFluxDiT: the modified Flux DiT forward (concept-token stream included) on MI355X.
+
+Host-side mirror of the reference's model object for this path:
+  * ``ModifiedFluxDiT.forward``              concept_attention/modified_flux_dit.py:75-163
+  * ``ModifiedDoubleStreamBlock.forward``    concept_attention/modified_double_stream_block.py:69-204
+  * ``ModifiedSingleStreamBlock.forward``    concept_attention/modified_single_stream_block.py:43-56
+It keeps the call contract ``denoise`` (flux/sampling.py:126-139) and ``encode_image``
+(concept_attention_pipeline.py:284-297) rely on -- same keyword names, ``(pred | None, dict)``
+return value with the four reference keys stacked over the double blocks -- so it can be passed
+wherever the reference takes a ``dit_class`` instance.  All arithmetic runs in the gfx950
+kernels of libconceptattn.so (conceptattention_amd.ops); PyTorch provides device memory only.
+
+Data layout in HBM (one resident activation set per model instance, batch 1):
+  X    [C+T+L, H]   bf16 residual streams, rows = [concept tokens | text tokens | image tokens]
+  XM   [C+T+L, H]   LayerNorm+modulated input of the next projection
+  QKV  [C+T+L, 3H]  projection output, q|k|v thirds, head-major inside a third
+  ATT  [C+T+L, H]   attention output, head-concatenated
+  HID  [C+T+L, 4H]  MLP hidden of the double blocks
+  CAT  [T+L, 5H]    single blocks: [attention | gelu(mlp)] input of linear2
+With this row order the text-weight projections see [concepts|text] as one contiguous matrix
+(the concept stream re-uses the text weights, modified_double_stream_block.py:100-104), the
+single blocks see [text|image] as one contiguous matrix (modified_flux_dit.py:149), and the
+concept attention reads [concept keys | image keys] as two row segments without any copy.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Iterable, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .params import FluxParams
+from .weights import iter_synthetic_state_dict, state_dict_spec
+
+DICT_KEYS = (
+    "output_space_concept_vectors",
+    "output_space_image_vectors",
+    "cross_attention_concept_vectors",
+    "cross_attention_image_vectors",
+)
+
+
+class FluxWeights:
+    """bf16 device weights under the BFL state-dict names.  The adaLN modulation matrices of all
+    blocks live in ONE stacked buffer so a diffusion step computes every block's
+    shift/scale/gate with a single weight-streaming launch."""
+
+    def __init__(self, params: FluxParams, device):
+        self.params = params
+        self.device = torch.device(device)
+        H = params.hidden_size
+        self.tensors: dict[str, torch.Tensor] = {}
+        mod_names = []
+        for i in range(params.depth):
+            mod_names += [(f"double_blocks.{i}.img_mod.lin", 6 * H), (f"double_blocks.{i}.txt_mod.lin", 6 * H)]
+        for i in range(params.depth_single_blocks):
+            mod_names.append((f"single_blocks.{i}.modulation.lin", 3 * H))
+        mod_names.append(("final_layer.adaLN_modulation.1", 2 * H))
+        self.mod_offset: dict[str, int] = {}
+        off = 0
+        for name, n in mod_names:
+            self.mod_offset[name] = off
+            off += n
+        self.mod_rows = off
+        self.mod_w = torch.empty(off, H, device=self.device, dtype=torch.bfloat16)
+        self.mod_b = torch.empty(off, device=self.device, dtype=torch.bfloat16)
+        for name, shape in state_dict_spec(params):
+            base, kind = name.rsplit(".", 1)
+            if base in self.mod_offset:
+                o = self.mod_offset[base]
+                src = self.mod_w if kind == "weight" else self.mod_b
+                self.tensors[name] = src[o:o + shape[0]]
+            else:
+                self.tensors[name] = torch.empty(shape, device=self.device, dtype=torch.bfloat16)
+
+    def __getitem__(self, name: str) -> torch.Tensor:
+        return self.tensors[name]
+
+    def state_dict(self) -> dict[str, torch.Tensor]:
+        return dict(self.tensors)
+
+    def load_state_dict(self, sd, strict: bool = True):
+        """Copy tensors in (any float dtype / device).  Same (missing, unexpected) semantics as
+        nn.Module.load_state_dict (the reference calls it with strict=False,
+        concept_attention/image_generator.py:44)."""
+        missing = [k for k in self.tensors if k not in sd]
+        unexpected = [k for k in sd if k not in self.tensors]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:4]}.. unexpected {unexpected[:4]}..")
+        for k, t in self.tensors.items():
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(t.shape):
+                    raise RuntimeError(f"load_state_dict: {k} has shape {tuple(sd[k].shape)}, expected {tuple(t.shape)}")
+                t.copy_(sd[k])
+        return missing, unexpected
+
+    def init_synthetic(self, seed: int = 0, on_device: bool = True):
+        """Random-init weights of the right geometry.  on_device=True draws on
+        the GPU (fast, 23.8 GB for full Flux); False draws on the CPU generator so the values
+        are identical to ``weights.synthetic_state_dict`` (used by the parity tests)."""
+        dev = self.device if on_device else "cpu"
+        for name, t in iter_synthetic_state_dict(self.params, seed=seed, device=dev, dtype=torch.float32):
+            self.tensors[name].copy_(t)
+        return self
+
+
+@dataclass
+class HeatmapRequest:
+    """Fused heat-map accumulation (replaces materialising the 478 MB/step dicts that
+    compute_heatmaps_from_vectors later slices, concept_attention_pipeline.py:57-82)."""
+    layer_indices: tuple
+    weight: float                 # 1 / (|timesteps| * |layers|)
+    out_space: torch.Tensor       # fp32 [C, L] accumulator (output-space maps)
+    cross_space: torch.Tensor     # fp32 [C, L] accumulator (cross-attention-space maps)
+
+
+class HipFluxDiT:
+    """Drop-in for the reference's ``ModifiedFluxDiT`` instance on the hot path (inference only)."""
+
+    def __init__(self, params: FluxParams, device="cuda:0", weights: Optional[FluxWeights] = None,
+                 attention_block_class=None):
+        # attention_block_class is accepted for signature compatibility with
+        # ModifiedFluxDiT(params, attention_block_class=...) (modified_flux_dit.py:34); the HIP
+        # path has exactly one block implementation.
+        if params.head_dim != 128:
+            raise ValueError("HipFluxDiT: the gfx950 kernels are built for head_dim 128")
+        self.params = params
+        self.device = torch.device(device)
+        self.in_channels = params.in_channels
+        self.out_channels = params.in_channels
+        self.hidden_size = params.hidden_size
+        self.num_heads = params.num_heads
+        L.load()
+        self.weights = weights if weights is not None else FluxWeights(params, self.device)
+        self._ws_key = None
+        self._rope_key = None
+
+    # ---- nn.Module-like surface the reference's loader touches (image_generator.py:37-44,183,194)
+    def load_state_dict(self, sd, strict: bool = True, assign: bool = False):
+        return self.weights.load_state_dict(sd, strict=strict)
+
+    def state_dict(self):
+        return self.weights.state_dict()
+
+    def to(self, *a, **k):
+        return self
+
+    def cpu(self):  # the reference round-trips 23.8 GB per call (image_generator.py:183,194); we keep it resident
+        return self
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, L_img: int, T: int, C: int):
+        key = (L_img, T, C)
+        if self._ws_key == key:
+            return
+        p, dev = self.params, self.device
+        H, MLP = p.hidden_size, p.mlp_hidden
+        n = C + T + L_img
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.X = torch.zeros(n, H, **bf)
+        self.XM = torch.zeros(n, H, **bf)
+        self.QKV = torch.zeros(n, 3 * H, **bf)
+        self.ATT = torch.zeros(n, H, **bf)
+        self.HID = torch.zeros(n, MLP, **bf)
+        self.CAT = torch.zeros(T + L_img, H + MLP, **bf)
+        self.QPRE = torch.zeros(n, H, **bf)
+        self.ATT32 = torch.zeros(max(C, 1), H, **f32)  # fp32 copy of the concept attention rows
+        self.TXT_IN = torch.zeros(C + T, p.context_in_dim, **bf)
+        self.PRED = torch.zeros(L_img, p.in_channels, **bf)
+        self.ROPE = torch.zeros(n, 64, 2, **f32)
+        self.TEMB = torch.zeros(2, 256, **f32)
+        self.TVAL = torch.zeros(2, **f32)
+        self.YIN = torch.zeros(2, p.vec_in_dim, **f32)
+        self.HVEC = torch.zeros(2, H, **f32)
+        self.VEC = torch.zeros(2, H, **f32)
+        self.MOD = torch.zeros(2, self.weights.mod_rows, **f32)
+        self.LOGITS = torch.zeros(max(C, 1), L_img, **f32)
+        self._ws_key = key
+        self._rope_key = None
+
+    def _rope_table(self, img_ids, txt_ids, concept_ids, C, T):
+        """(cos, sin) per row in [concept | text | image] order.  rope(): angles in float64,
+        stored fp32 (flux/math.py:15-22); EmbedND concatenates the axes (layers.py:18-25)."""
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (img_ids, txt_ids, concept_ids))
+        if self._rope_key == key:
+            return
+        ids = torch.cat((concept_ids[0], txt_ids[0], img_ids[0]), 0).to(self.device, torch.float64)
+        col = 0
+        for a, d in enumerate(self.params.axes_dim):
+            scale = torch.arange(0, d, 2, dtype=torch.float64, device=self.device) / d
+            omega = 1.0 / (self.params.theta ** scale)
+            ang = ids[:, a:a + 1] * omega[None]
+            self.ROPE[:, col:col + d // 2, 0] = torch.cos(ang).float()
+            self.ROPE[:, col:col + d // 2, 1] = torch.sin(ang).float()
+            col += d // 2
+        self._rope_key = key
+
+    def _mod(self, name: str, row: int, chunk: int) -> torch.Tensor:
+        """fp32 view of one modulation chunk: name = '<block>.lin' base, row 0 = vec, 1 = concept_vec."""
+        H = self.hidden_size
+        o = self.weights.mod_offset[name] + chunk * H
+        return self.MOD[row, o:o + H]
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def __call__(self, img, img_ids, txt, txt_ids, concepts, concept_ids, concept_vec, timesteps, y,
+                 guidance=None, stop_after_multimodal_attentions: bool = False, edit_metadata=None,
+                 iteration=None, joint_attention_kwargs=None, return_vectors: bool = True,
+                 heatmaps: Optional[HeatmapRequest] = None, **kwargs):
+        """Same keyword contract as ModifiedFluxDiT.forward (modified_flux_dit.py:75-92).
+
+        Extra (HIP-path) keywords: ``return_vectors=False`` skips materialising the four
+        per-layer vector stacks (the dict is then empty); ``heatmaps`` accumulates
+        softmax-over-concepts maps for the requested layers inside the forward."""
+        assert concept_vec is not None, "Concept vectors must be provided for this implementation."
+        if img.ndim != 3 or txt.ndim != 3:
+            raise ValueError("Input img and txt tensors must have 3 dimensions.")
+        if img.shape[0] != 1 or txt.shape[0] != 1 or concepts.shape[0] != 1:
+            raise NotImplementedError("HipFluxDiT: batch size 1 only (the reference path is B=1 as well)")
+        p, W = self.params, self.weights
+        if p.guidance_embed and guidance is None:
+            raise ValueError("Didn't get guidance strength for guidance distilled model.")
+        H, NH, MLP = p.hidden_size, p.num_heads, p.mlp_hidden
+        Li, T, C = img.shape[1], txt.shape[1], concepts.shape[1]
+        self._workspace(Li, T, C)
+        self._rope_table(img_ids, txt_ids, concept_ids, C, T)
+        n = C + T + Li
+        CT = C + T
+        X, XM, QKV, ATT, HID, CAT = self.X, self.XM, self.QKV, self.ATT, self.HID, self.CAT
+        bf = torch.bfloat16
+
+        # ---- input embeddings: img_in, txt_in (text and concept tokens share txt_in, :105,120)
+        self.TXT_IN[:C].copy_(concepts[0])
+        self.TXT_IN[C:].copy_(txt[0])
+        img_in = img[0].to(bf).contiguous()
+        ops.gemm([ops.Gemm(img_in, W["img_in.weight"], W["img_in.bias"], X[CT:]),
+                  ops.Gemm(self.TXT_IN, W["txt_in.weight"], W["txt_in.bias"], X[:CT])])
+
+        # ---- conditioning vectors: row 0 = vec (y), row 1 = concept_vec (modified_flux_dit.py:99-119)
+        self.TVAL.copy_(timesteps.reshape(-1)[:1].float().expand(2))
+        ops.timestep_embedding(self.TVAL, self.TEMB)
+        ops.gemv(self.TEMB, W["time_in.in_layer.weight"], W["time_in.in_layer.bias"], self.HVEC)
+        ops.gemv(self.HVEC, W["time_in.out_layer.weight"], W["time_in.out_layer.bias"], self.VEC, silu_input=True)
+        if p.guidance_embed:
+            self.TVAL.copy_(guidance.reshape(-1)[:1].float().expand(2))
+            ops.timestep_embedding(self.TVAL, self.TEMB)
+            ops.gemv(self.TEMB, W["guidance_in.in_layer.weight"], W["guidance_in.in_layer.bias"], self.HVEC)
+            ops.gemv(self.HVEC, W["guidance_in.out_layer.weight"], W["guidance_in.out_layer.bias"], self.VEC,
+                     silu_input=True, accumulate=True)
+        self.YIN[0].copy_(y.reshape(-1))
+        self.YIN[1].copy_(concept_vec.reshape(-1))
+        ops.gemv(self.YIN, W["vector_in.in_layer.weight"], W["vector_in.in_layer.bias"], self.HVEC)
+        ops.gemv(self.HVEC, W["vector_in.out_layer.weight"], W["vector_in.out_layer.bias"], self.VEC,
+                 silu_input=True, accumulate=True)
+        self._modulations()
+
+        out = {k: [] for k in DICT_KEYS} if return_vectors else {}
+        for i in range(p.depth):
+            self._double_block(i, C, T, Li, joint_attention_kwargs, out, return_vectors, heatmaps)
+        if return_vectors:
+            out = {k: torch.stack(v, 0) for k, v in out.items()}
+        if stop_after_multimodal_attentions:
+            return None, out
+        for i in range(p.depth_single_blocks):
+            self._single_block(i, C, T, Li)
+
+        # ---- LastLayer on the image rows (flux/modules/layers.py:242-253)
+        fm = "final_layer.adaLN_modulation.1"
+        ops.ln_modulate(X[CT:], XM[CT:], [(Li, self._mod(fm, 0, 0), self._mod(fm, 0, 1))])
+        ops.gemm([ops.Gemm(XM[CT:], W["final_layer.linear.weight"], W["final_layer.linear.bias"], self.PRED)])
+        return self.PRED.unsqueeze(0).clone(), out
+
+    def _modulations(self):
+        """Every block's adaLN shift/scale/gate from VEC (row 0 = vec, row 1 = concept_vec) in one
+        weight-streaming launch (Modulation, flux/modules/layers.py:113-126)."""
+        ops.gemv(self.VEC, self.weights.mod_w, self.weights.mod_b, self.MOD, silu_input=True)
+
+    def _double_block(self, i, C, T, Li, joint_attention_kwargs=None, out=None, return_vectors=False,
+                      heatmaps=None):
+        """ModifiedDoubleStreamBlock.forward (modified_double_stream_block.py:69-204) on the
+        resident X rows [concepts | text | image]; 8 launches."""
+        p, W = self.params, self.weights
+        H, NH = p.hidden_size, p.num_heads
+        CT, n = C + T, C + T + Li
+        X, XM, QKV, ATT, HID = self.X, self.XM, self.QKV, self.ATT, self.HID
+        qs, ks, vs = QKV[:, :H], QKV[:, H:2 * H], QKV[:, 2 * H:]
+        cross = self_ = True
+        if joint_attention_kwargs is not None:
+            cross = joint_attention_kwargs.get("concept_cross_attention", True)
+            self_ = joint_attention_kwargs.get("concept_self_attention", True)
+        b = f"double_blocks.{i}."
+        im, tm = b + "img_mod.lin", b + "txt_mod.lin"
+        capture = return_vectors or (heatmaps is not None and i in heatmaps.layer_indices)
+        # K4: LayerNorm + (1+scale)*x+shift, three row segments (:88-89,94-95,100-101)
+        ops.ln_modulate(X, XM, [(C, self._mod(tm, 1, 0), self._mod(tm, 1, 1)),
+                                (CT, self._mod(tm, 0, 0), self._mod(tm, 0, 1)),
+                                (n, self._mod(im, 0, 0), self._mod(im, 0, 1))])
+        # K5: qkv projections, image stream + [concept|text] stream in one grouped launch
+        ops.gemm([ops.Gemm(XM[CT:], W[b + "img_attn.qkv.weight"], W.tensors.get(b + "img_attn.qkv.bias"), QKV[CT:]),
+                  ops.Gemm(XM[:CT], W[b + "txt_attn.qkv.weight"], W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:CT])])
+        # K6+K7: QK-RMSNorm then RoPE in place; pre-RoPE q kept for the cross-attention maps
+        ops.qknorm_rope(QKV, NH, [(CT, W[b + "txt_attn.norm.query_norm.scale"], W[b + "txt_attn.norm.key_norm.scale"]),
+                                  (n, W[b + "img_attn.norm.query_norm.scale"], W[b + "img_attn.norm.key_norm.scale"])],
+                        self.ROPE, q_prerope=self.QPRE if capture else None)
+        # K8+K9: joint text+image attention and the concept rows in one launch
+        probs = [ops.Attn(qs[C:], ATT[C:], ks[C:], vs[C:])]
+        if C > 0:
+            if cross and self_:
+                probs.append(ops.Attn(qs[:C], ATT[:C], ks[:C], vs[:C], ks[CT:], vs[CT:], out_f32=self.ATT32[:C]))
+            elif cross:   # :129-138 image keys/values only
+                probs.append(ops.Attn(qs[:C], ATT[:C], ks[CT:], vs[CT:], out_f32=self.ATT32[:C]))
+            elif self_:   # :139-147 concept keys/values only
+                probs.append(ops.Attn(qs[:C], ATT[:C], ks[:C], vs[:C], out_f32=self.ATT32[:C]))
+            else:         # :157-159 concept_attn = concept_v
+                ATT[:C].copy_(vs[:C])
+                self.ATT32[:C].copy_(vs[:C])
+        ops.attention(probs, NH)
+        if capture:
+            self._capture(out, i, C, CT, n, NH, return_vectors, heatmaps)
+        # K12: proj + gated residual (:194,198,201); concept rows use txt weights + concept gate
+        ops.gemm([ops.Gemm(ATT[CT:], W[b + "img_attn.proj.weight"], W[b + "img_attn.proj.bias"], X[CT:],
+                           L.EPI_GATE_RESIDUAL, resid=X[CT:], gate=self._mod(im, 0, 2)),
+                  ops.Gemm(ATT[:CT], W[b + "txt_attn.proj.weight"], W[b + "txt_attn.proj.bias"], X[:CT],
+                           L.EPI_GATE_RESIDUAL, resid=X[:CT], gate=self._mod(tm, 1, 2), gate2=self._mod(tm, 0, 2),
+                           gate_rows=C)])
+        # K13: LN + modulate + MLP + gated residual (:196,199,202)
+        ops.ln_modulate(X, XM, [(C, self._mod(tm, 1, 3), self._mod(tm, 1, 4)),
+                                (CT, self._mod(tm, 0, 3), self._mod(tm, 0, 4)),
+                                (n, self._mod(im, 0, 3), self._mod(im, 0, 4))])
+        ops.gemm([ops.Gemm(XM[CT:], W[b + "img_mlp.0.weight"], W[b + "img_mlp.0.bias"], HID[CT:], L.EPI_GELU_TANH),
+                  ops.Gemm(XM[:CT], W[b + "txt_mlp.0.weight"], W[b + "txt_mlp.0.bias"], HID[:CT], L.EPI_GELU_TANH)])
+        ops.gemm([ops.Gemm(HID[CT:], W[b + "img_mlp.2.weight"], W[b + "img_mlp.2.bias"], X[CT:],
+                           L.EPI_GATE_RESIDUAL, resid=X[CT:], gate=self._mod(im, 0, 5)),
+                  ops.Gemm(HID[:CT], W[b + "txt_mlp.2.weight"], W[b + "txt_mlp.2.bias"], X[:CT],
+                           L.EPI_GATE_RESIDUAL, resid=X[:CT], gate=self._mod(tm, 1, 5), gate2=self._mod(tm, 0, 5),
+                           gate_rows=C)])
+
+    def _single_block(self, i, C, T, Li):
+        """ModifiedSingleStreamBlock.forward (modified_single_stream_block.py:43-56) on the
+        [text | image] rows; 5 launches."""
+        p, W = self.params, self.weights
+        H, NH = p.hidden_size, p.num_heads
+        xs, xms, qkvs, CAT = self.X[C:], self.XM[C:], self.QKV[C:], self.CAT
+        b = f"single_blocks.{i}."
+        m = b + "modulation.lin"
+        ops.ln_modulate(xs, xms, [(T + Li, self._mod(m, 0, 0), self._mod(m, 0, 1))])
+        ops.gemm([ops.Gemm(xms, W[b + "linear1.weight"], W[b + "linear1.bias"], qkvs, L.EPI_SPLIT_GELU,
+                           out2=CAT[:, H:], n_split=3 * H)])
+        ops.qknorm_rope(qkvs, NH, [(T + Li, W[b + "norm.query_norm.scale"], W[b + "norm.key_norm.scale"])],
+                        self.ROPE[C:])
+        ops.attention([ops.Attn(qkvs[:, :H], CAT[:, :H], qkvs[:, H:2 * H], qkvs[:, 2 * H:])], NH)
+        ops.gemm([ops.Gemm(CAT, W[b + "linear2.weight"], W[b + "linear2.bias"], xs, L.EPI_GATE_RESIDUAL,
+                           resid=xs, gate=self._mod(m, 0, 2))])
+
+    forward = __call__
+
+    def _capture(self, out, layer, C, CT, n, NH, return_vectors, heatmaps):
+        """Dict capture (modified_double_stream_block.py:185-191) and/or fused heat-map update."""
+        ATT, QPRE = self.ATT, self.QPRE
+        if heatmaps is not None and layer in heatmaps.layer_indices:
+            # output space: the C concept rows come from the fp32 copy the attention kernel wrote
+            # (their bf16 rounding, multiplied by the large component all attention outputs share,
+            # is the dominant heat-map error otherwise -- DESIGN.md "tolerance")
+            for img_vec, con_vec, acc in ((ATT[CT:], self.ATT32[:C], heatmaps.out_space),
+                                          (QPRE[CT:], QPRE[:C], heatmaps.cross_space)):
+                ops.heatmap_logits(img_vec, con_vec, self.LOGITS[:C])
+                ops.heatmap_softmax_accumulate(self.LOGITS[:C], acc, heatmaps.weight)
+        if return_vectors:
+            H = self.hidden_size
+            out["output_space_concept_vectors"].append(ATT[:C].clone()[None])
+            out["output_space_image_vectors"].append(ATT[CT:].clone()[None])
+            # the reference stores post-QKNorm, pre-RoPE q per head: [B, heads, tokens, 128]; in the
+            # self-attention-only ablation it rebinds concept_q to the post-RoPE tensor (:140), which
+            # for the all-zero concept ids is the same values
+            cq = QPRE[:C].view(C, NH, 128).permute(1, 0, 2).contiguous()[None]
+            iq = QPRE[CT:].view(n - CT, NH, 128).permute(1, 0, 2).contiguous()[None]
+            out["cross_attention_concept_vectors"].append(cq)
+            out["cross_attention_image_vectors"].append(iq)

@@ -94,6 +94,7 @@ class Attn:
     v0: torch.Tensor
     k1: Optional[torch.Tensor] = None
     v1: Optional[torch.Tensor] = None
+    out_f32: Optional[torch.Tensor] = None  # optional fp32 copy of the output rows
 
 
 def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] = None) -> None:
@@ -113,6 +114,11 @@ def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] =
             if a.k1.stride(0) != p.ldkv or a.v1.stride(0) != p.ldkv or a.v1.shape[0] != a.k1.shape[0]:
                 raise ValueError(f"attention[{i}]: both key/value segments must share one row stride")
             p.k1, p.v1, p.n1 = a.k1.data_ptr(), a.v1.data_ptr(), a.k1.shape[0]
+        if a.out_f32 is not None:
+            _chk(a.out_f32, torch.float32, "out_f32")
+            if a.out_f32.shape[0] != p.nq:
+                raise ValueError(f"attention[{i}]: out_f32 row mismatch")
+            p.out_f32, p.ldo32 = a.out_f32.data_ptr(), a.out_f32.stride(0)
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
     L.check(lib.ca_attn_fwd_bf16(arr, len(problems), num_heads, scale, _stream()), "ca_attn_fwd_bf16")
@@ -164,15 +170,19 @@ def gemv(x, w, bias, out, silu_input=False, accumulate=False) -> None:
 
 
 def heatmap_logits(img_vec, con_vec, logits) -> None:
-    """logits[c,p] = <img_vec[p,:], con_vec[c,:]>; bf16 [L,dim], [C,dim] -> fp32 [C,L]."""
+    """logits[c,p] = <img_vec[p,:], con_vec[c,:]>; img bf16 [L,dim], con bf16|fp32 [C,dim] -> fp32 [C,L]."""
     lib = L.load()
-    _chk(img_vec, torch.bfloat16, "img_vec"), _chk(con_vec, torch.bfloat16, "con_vec")
+    _chk(img_vec, torch.bfloat16, "img_vec")
+    if con_vec.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("heatmap_logits: con_vec must be bf16 or fp32")
+    _chk(con_vec, con_vec.dtype, "con_vec")
     _chk(logits, torch.float32, "logits")
     Lp, dim, Cc = img_vec.shape[0], img_vec.shape[1], con_vec.shape[0]
     if tuple(logits.shape) != (Cc, Lp) or not logits.is_contiguous() or con_vec.shape[1] != dim:
         raise ValueError("heatmap_logits: shape mismatch")
     L.check(lib.ca_heatmap_logits_bf16(img_vec.data_ptr(), img_vec.stride(0), con_vec.data_ptr(), con_vec.stride(0),
-                                       Lp, Cc, dim, logits.data_ptr(), _stream()), "ca_heatmap_logits_bf16")
+                                       int(con_vec.dtype == torch.float32), Lp, Cc, dim, logits.data_ptr(),
+                                       _stream()), "ca_heatmap_logits_bf16")
 
 
 def heatmap_softmax_accumulate(logits, acc, weight: float) -> None:
@@ -191,3 +201,13 @@ def axpy(x, y, a: float) -> None:
     if not (x.is_contiguous() and y.is_contiguous()) or x.numel() != y.numel():
         raise ValueError("axpy: x,y must be contiguous with equal sizes")
     L.check(lib.ca_axpy_bf16(x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream()), "ca_axpy_bf16")
+
+
+def timestep_embedding(t, out, time_factor: float = 1000.0, max_period: float = 10000.0) -> None:
+    """out[v,:] = [cos(tf*t[v]*f), sin(tf*t[v]*f)]; t fp32 [nt], out fp32 [nt, dim] contiguous."""
+    lib = L.load()
+    _chk(t, torch.float32, "t"), _chk(out, torch.float32, "out")
+    if out.dim() != 2 or out.shape[0] != t.shape[0] or not out.is_contiguous():
+        raise ValueError("timestep_embedding: out must be contiguous [nt, dim]")
+    L.check(lib.ca_timestep_embedding_f32(t.data_ptr(), t.shape[0], out.data_ptr(), out.shape[1], time_factor,
+                                          max_period, _stream()), "ca_timestep_embedding_f32")

@@ -1,0 +1,222 @@
+"""ConceptAttentionFluxPipeline on MI355X: same public surface as the reference's
+``concept_attention/concept_attention_pipeline.py:94-357`` (constructor arguments, ``generate_image``
+and ``encode_image`` signatures and defaults, ``ConceptAttentionPipelineOutput``), running the DiT
+and the heat-map reduction in the gfx950 kernels.
+
+Out of scope: the T5/CLIP text encoders and the VAE need checkpoints that
+are not available offline.  They are injectable (``text_encoder`` / ``autoencoder``); without them
+the pipeline runs in *synthetic conditioning* mode -- prompt and concept strings are mapped to
+seeded N(0,1) embeddings of the right shapes and ``image`` is returned as the unpacked latent --
+which is exactly the configuration BASELINE.json measures.
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import sampling
+from .flux_dit import FluxWeights, HeatmapRequest, HipFluxDiT
+from .heatmaps import compute_heatmaps_from_vectors
+from .params import T5_TOKENS, configs
+
+
+@dataclass
+class ConceptAttentionPipelineOutput:
+    """concept_attention_pipeline.py:20-24."""
+    image: object  # PIL.Image.Image | np.ndarray
+    concept_heatmaps: list
+    cross_attention_maps: list
+
+
+class SyntheticTextEncoder:
+    """Stand-in for HFEmbedder (flux/modules/conditioner.py): deterministic N(0,1) embeddings
+    keyed by the text, T5-like (1,T,4096) and CLIP-like pooled (1,768)."""
+
+    def __init__(self, n_tokens: int, context_dim: int = 4096, vec_dim: int = 768, device="cuda:0"):
+        self.n_tokens, self.context_dim, self.vec_dim, self.device = n_tokens, context_dim, vec_dim, device
+
+    def _gen(self, text: str, salt: int):
+        g = torch.Generator(device="cpu")
+        g.manual_seed((zlib.crc32(text.encode()) * 31 + salt) & 0x7FFFFFFF)
+        return g
+
+    def t5(self, text: str) -> torch.Tensor:
+        return torch.randn(1, self.n_tokens, self.context_dim, generator=self._gen(text, 1)).to(
+            self.device, torch.bfloat16)
+
+    def clip(self, text: str) -> torch.Tensor:
+        return torch.randn(1, self.vec_dim, generator=self._gen(text, 2)).to(self.device, torch.bfloat16)
+
+
+def colorize_heatmaps(heatmaps: np.ndarray, cmap: str = "plasma") -> list:
+    """Global min-max over ALL concepts, matplotlib colormap, uint8 RGB -> PIL
+    (concept_attention_pipeline.py:174-196)."""
+    import matplotlib.pyplot as plt
+    import PIL.Image
+    lo, hi = heatmaps.min(), heatmaps.max()
+    out = []
+    for hm in heatmaps:
+        hm = (hm - lo) / (hi - lo)
+        rgb = (plt.get_cmap(cmap)(hm)[:, :, :3] * 255).astype(np.uint8)
+        out.append(PIL.Image.fromarray(rgb))
+    return out
+
+
+class ConceptAttentionFluxPipeline:
+    def __init__(self, model_name: str = "flux-schnell", offload_model: bool = False, device="cuda:0",
+                 weights="synthetic", weight_seed: int = 0, text_encoder=None, autoencoder=None,
+                 params=None, n_text_tokens: Optional[int] = None):
+        """model_name / offload_model / device as in the reference (:100-113).  ``weights`` is
+        "synthetic" (seeded random init), a path to a flux1-*.safetensors file, or a state dict."""
+        if params is None and model_name not in configs:
+            raise KeyError(model_name)
+        self.model_name = model_name
+        self.offload_model = offload_model
+        self.device = torch.device(device)
+        self.is_schnell = model_name == "flux-schnell"
+        self.params = params if params is not None else configs[model_name]
+        self.model = HipFluxDiT(self.params, self.device)
+        if isinstance(weights, str) and weights == "synthetic":
+            self.model.weights.init_synthetic(weight_seed)
+        elif isinstance(weights, str):
+            from safetensors.torch import load_file
+            self.model.load_state_dict(load_file(weights, device=str(self.device)), strict=False)
+        elif weights is not None:
+            self.model.load_state_dict(weights, strict=False)
+        n_tok = n_text_tokens or T5_TOKENS.get(model_name, 256)
+        self.text_encoder = text_encoder or SyntheticTextEncoder(n_tok, self.params.context_in_dim,
+                                                                 self.params.vec_in_dim, self.device)
+        self.autoencoder = autoencoder
+
+    # ------------------------------------------------------------------ conditioning
+    def _embed(self, prompt: str, concepts: Sequence[str]):
+        te = self.text_encoder
+        txt, vec = te.t5(prompt), te.clip(prompt)
+        # embed_concepts (concept_attention/utils.py:6-33): first T5 token of each concept
+        con = torch.stack([te.t5(c)[0, 0, :] for c in concepts]).unsqueeze(0)
+        con, con_ids, con_vec = sampling.concept_inputs(con, vec)
+        return txt, vec, con, con_ids, con_vec
+
+    def _finish(self, image, concept_heatmaps, cross_attention_maps, return_pil_heatmaps, cmap):
+        concept_heatmaps = concept_heatmaps.to(torch.float32).detach().cpu().numpy()[0]
+        cross_attention_maps = cross_attention_maps.to(torch.float32).detach().cpu().numpy()[0]
+        if return_pil_heatmaps:
+            concept_heatmaps = colorize_heatmaps(concept_heatmaps, cmap)
+            cross_attention_maps = colorize_heatmaps(cross_attention_maps, cmap)
+        return ConceptAttentionPipelineOutput(image=image, concept_heatmaps=concept_heatmaps,
+                                              cross_attention_maps=cross_attention_maps)
+
+    def _decode(self, x: torch.Tensor, height: int, width: int):
+        lat = sampling.unpack(x.float(), height, width)
+        if self.autoencoder is None:
+            return lat[0].cpu().numpy()
+        import PIL.Image
+        img = self.autoencoder.decode(lat.to(torch.float32)).clamp(-1, 1)[0].permute(1, 2, 0)
+        return PIL.Image.fromarray((127.5 * (img + 1.0)).cpu().byte().numpy())
+
+    # ------------------------------------------------------------------ generate_image (:115-202)
+    @torch.no_grad()
+    def generate_image(self, prompt: str, concepts: list, width: int = 1024, height: int = 1024,
+                       return_cross_attention=False, layer_indices=list(range(15, 19)),
+                       return_pil_heatmaps=True, seed: int = 0, num_inference_steps: int = 4,
+                       guidance: float = 0.0, timesteps=None, softmax: bool = True,
+                       attention_norm: str = "sparsemax", cmap="plasma", latent: Optional[torch.Tensor] = None,
+                       fused: bool = True) -> ConceptAttentionPipelineOutput:
+        """``latent`` (1,16,h/8,w/8) overrides get_noise (device RNG differs between platforms);
+        ``fused=False`` takes the reference's route (stack the per-layer vectors, then reduce)."""
+        assert return_cross_attention is False, "Not supported yet"
+        assert all([0 <= li < self.params.depth for li in layer_indices]), "Invalid layer index"
+        assert height == width, "Height and width must be the same for now"
+        if not (softmax or attention_norm == "softmax"):
+            raise NotImplementedError("only the softmax branch is supported (entmax is unpinned)")
+        if timesteps is None:
+            timesteps = list(range(num_inference_steps))
+        x = latent if latent is not None else sampling.get_noise(1, height, width, self.device, torch.bfloat16, seed)
+        x = x.to(self.device, torch.bfloat16)
+        schedule = sampling.get_schedule(num_inference_steps, x.shape[-1] * x.shape[-2] // 4,
+                                         shift=(not self.is_schnell))
+        txt, vec, con, con_ids, con_vec = self._embed(prompt, concepts)
+        inp = sampling.prepare_from_embeddings(x, txt, vec)
+        C, n_patches = con.shape[1], inp["img"].shape[1]
+        if fused:
+            ts = [int(t) for t in timesteps]
+            req = HeatmapRequest(tuple(int(l) for l in layer_indices), 1.0 / (len(ts) * len(layer_indices)),
+                                 torch.zeros(C, n_patches, device=self.device),
+                                 torch.zeros(C, n_patches, device=self.device))
+            # repeated indices weigh a (step, layer) pair repeatedly, as indexing does in the reference
+            img = None
+            counts = {t: ts.count(t) for t in set(ts)}
+            lcounts = {l: list(layer_indices).count(l) for l in set(layer_indices)}
+            if any(v > 1 for v in counts.values()) or any(v > 1 for v in lcounts.values()):
+                fused = False
+            else:
+                img, _, _ = sampling.denoise(self.model, **inp, timesteps=schedule, guidance=guidance,
+                                             concepts=con, concept_ids=con_ids, concept_vec=con_vec,
+                                             return_intermediate_images=False, return_vectors=False,
+                                             heatmaps=req, heatmap_timesteps=ts)
+                side = int(round(n_patches ** 0.5))
+                concept_heatmaps = req.out_space.view(1, C, side, side)
+                cross_attention_maps = req.cross_space.view(1, C, side, side)
+        if not fused:
+            img, _, d = sampling.denoise(self.model, **inp, timesteps=schedule, guidance=guidance, concepts=con,
+                                         concept_ids=con_ids, concept_vec=con_vec,
+                                         return_intermediate_images=False)
+            cross_attention_maps = compute_heatmaps_from_vectors(
+                d["cross_attention_image_vectors"], d["cross_attention_concept_vectors"],
+                layer_indices=layer_indices, timesteps=timesteps, softmax=softmax, attention_norm=attention_norm)
+            concept_heatmaps = compute_heatmaps_from_vectors(
+                d["output_space_image_vectors"], d["output_space_concept_vectors"],
+                layer_indices=layer_indices, timesteps=timesteps, softmax=softmax, attention_norm=attention_norm)
+        image = self._decode(img, height, width)
+        return self._finish(image, concept_heatmaps, cross_attention_maps, return_pil_heatmaps, cmap)
+
+    # ------------------------------------------------------------------ encode_image (:204-357)
+    @torch.no_grad()
+    def encode_image(self, image, concepts: list, prompt: str = "", width: int = 1024, height: int = 1024,
+                     layer_indices=list(range(15, 19)), num_samples: int = 1, num_steps: int = 4,
+                     noise_timestep: int = 2, device: str = "cuda:0", return_pil_heatmaps: bool = True,
+                     seed: int = 0, cmap="plasma", stop_after_multi_modal_attentions=True,
+                     attention_norm: str = "sparsemax", softmax=True) -> ConceptAttentionPipelineOutput:
+        """``image``: a latent tensor (1,16,h/8,w/8), or a PIL image when an autoencoder was injected.
+        One forward of the 19 double blocks per noise sample (stop_after_multimodal_attentions)."""
+        assert all([0 <= li < self.params.depth for li in layer_indices]), "Invalid layer index"
+        assert height == width, "Height and width must be the same for now"
+        if not (softmax or attention_norm == "softmax"):
+            raise NotImplementedError("only the softmax branch is supported (entmax is unpinned)")
+        if isinstance(image, torch.Tensor):
+            latent = image.to(self.device, torch.bfloat16)
+        elif self.autoencoder is not None:
+            arr = torch.from_numpy(np.asarray(image.convert("RGB"))).permute(2, 0, 1).float() / 255.0
+            arr = torch.nn.functional.interpolate((2.0 * arr - 1.0)[None].to(self.device), (height, width))
+            latent = self.autoencoder.encode(arr).to(torch.bfloat16)
+        else:
+            raise ValueError("encode_image needs a latent tensor or an injected autoencoder")
+        txt, vec, con, con_ids, con_vec = self._embed(prompt, concepts)
+        C = con.shape[1]
+        n_patches = (latent.shape[-1] // 2) * (latent.shape[-2] // 2)
+        # the reference indexes the stacked samples with the float schedule values
+        # (concept_attention_pipeline.py:311), which selects sample 0 only unless
+        # a value >= 1; here every sample contributes equally (identical at num_samples=1).
+        req = HeatmapRequest(tuple(int(l) for l in layer_indices), 1.0 / (num_samples * len(layer_indices)),
+                             torch.zeros(C, n_patches, device=self.device),
+                             torch.zeros(C, n_patches, device=self.device))
+        schedule = sampling.get_schedule(num_steps, n_patches, shift=(not self.is_schnell))
+        for i in range(num_samples):
+            # add_noise_to_image (concept_attention/segmentation.py:85-113)
+            noise = sampling.get_noise(1, height, width, self.device, torch.bfloat16, seed + i)
+            t = schedule[noise_timestep]
+            x = (t * noise.float() + (1.0 - t) * latent.float()).to(torch.bfloat16)
+            inp = sampling.prepare_from_embeddings(x, txt, vec)
+            t_vec = torch.full((1,), schedule[noise_timestep], device=self.device)
+            self.model(img=inp["img"], img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
+                       concepts=con, concept_ids=con_ids, concept_vec=con_vec, y=con_vec, timesteps=t_vec,
+                       guidance=torch.zeros(1, device=self.device),
+                       stop_after_multimodal_attentions=stop_after_multi_modal_attentions,
+                       joint_attention_kwargs=None, return_vectors=False, heatmaps=req)
+        side = int(round(n_patches ** 0.5))
+        return self._finish(image, req.out_space.view(1, C, side, side), req.cross_space.view(1, C, side, side),
+                            return_pil_heatmaps, cmap)

@@ -100,8 +100,10 @@ typedef struct {
   void *out;     /* bf16, row stride ldo */
   const void *k0, *v0; /* segment 0: n0 rows, row stride ldkv */
   const void *k1, *v1; /* segment 1: n1 rows, row stride ldkv */
+  float *out_f32; /* optional fp32 copy of the output rows (row stride ldo32), or NULL: used for the
+                     C concept rows so the heat-map products do not see their bf16 rounding */
   int32_t nq, n0, n1;
-  int32_t ldq, ldo, ldkv;
+  int32_t ldq, ldo, ldkv, ldo32;
 } ca_attn_problem;
 
 int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
@@ -159,10 +161,17 @@ int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void *W, const v
  *   acc[c,p]   += weight * softmax_c(logits[:,p])        (weight = 1/(|timesteps|*|layers|), :64-82)
  * fp32 accumulation (the reference does this in bf16; see DESIGN.md "tolerance").
  */
+/* con_vec is bf16 [C,dim] (con_is_f32 = 0) or fp32 [C,dim] (con_is_f32 = 1); ldc in elements. */
 int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const void *con_vec, int32_t ldc,
-                           int32_t L, int32_t C, int32_t dim, float *logits, ca_stream_t stream);
+                           int32_t con_is_f32, int32_t L, int32_t C, int32_t dim, float *logits,
+                           ca_stream_t stream);
 int ca_heatmap_softmax_accumulate(const float *logits, int32_t C, int32_t L, float weight, float *acc,
                                   ca_stream_t stream);
+
+/* Sinusoidal timestep embedding (timestep_embedding, flux/modules/layers.py:28-49):
+ * out[v, 0:dim/2] = cos(time_factor*t[v]*f_i), out[v, dim/2:] = sin(...), f_i = max_period^(-i/(dim/2)). */
+int ca_timestep_embedding_f32(const float *t, int32_t nt, float *out, int32_t dim, float time_factor,
+                              float max_period, ca_stream_t stream);
 
 /* Euler step of denoise(): x = x + a*y  (flux/sampling.py:141), bf16 in/out, fp32 math. */
 int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream);

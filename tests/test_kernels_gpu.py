@@ -137,12 +137,15 @@ def test_attention_two_segments_and_two_problems():
     H = nh * 128
     q, k, v = buf[:, :H], buf[:, H:2 * H], buf[:, 2 * H:]
     out = torch.zeros(C + T + Limg, H, device=DEV, dtype=torch.bfloat16)
+    out32 = torch.zeros(C, H, device=DEV)
     main = ops.Attn(q[C:], out[C:], k[C:], v[C:])
-    con = ops.Attn(q[:C], out[:C], k[:C], v[:C], k[C + T:], v[C + T:])
+    con = ops.Attn(q[:C], out[:C], k[:C], v[:C], k[C + T:], v[C + T:], out_f32=out32)
     ops.attention([main, con], nh)
     close(out[C:], attn_ref(q[C:], k[C:], v[C:], nh), atol=1e-2)
     kc, vc = torch.cat((k[:C], k[C + T:])), torch.cat((v[:C], v[C + T:]))
     close(out[:C], attn_ref(q[:C], kc, vc, nh), atol=1e-2)
+    assert torch.equal(out32.bfloat16(), out[:C])  # the fp32 copy rounds to the bf16 output
+    assert (out32 - attn_ref(q[:C], kc, vc, nh)).abs().max() < 3e-3  # only P's bf16 rounding left
 
 
 def test_attention_online_softmax_rescale_spike():
@@ -229,6 +232,9 @@ def test_heatmap_logits_softmax_accumulate(C):
     ops.heatmap_logits(img, con, logits)
     ref = con.float() @ img.float().t()
     assert (logits - ref).abs().max() < 1e-3 * max(1.0, ref.abs().max().item())
+    logits32 = torch.empty(C, Lp, device=DEV)
+    ops.heatmap_logits(img, con.float() * 1.001, logits32)  # fp32 concept vectors
+    assert (logits32 - 1.001 * ref).abs().max() < 1e-3 * max(1.0, ref.abs().max().item())
     acc = torch.full((C, Lp), 0.25, device=DEV)
     ops.heatmap_softmax_accumulate(logits, acc, 0.5)
     assert (acc - (0.25 + 0.5 * torch.softmax(ref, dim=0))).abs().max() < 1e-4

@@ -1,0 +1,200 @@
+"""The HIP model path against the CPU oracle / the reference's golden vectors (GPU box).
+
+Tolerance semantics (SURVEY.md §7 "hard parts"): the HIP path computes in bf16
+with fp32 accumulation; the oracle is fp32 on the SAME bf16-representable weights and inputs.
+Heat maps (softmax over concepts, values in [0,1]) must agree to <= 1e-3 max-abs per block;
+activations to a few bf16 ulps of their magnitude."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conceptattention_amd import ops  # noqa: E402
+from conceptattention_amd.flux_dit import DICT_KEYS, HeatmapRequest, HipFluxDiT  # noqa: E402
+from conceptattention_amd.heatmaps import compute_heatmaps_from_vectors  # noqa: E402
+from conceptattention_amd.params import FluxParams, tiny_params  # noqa: E402
+from conceptattention_amd.weights import synthetic_inputs, synthetic_state_dict  # noqa: E402
+from oracle import flux_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.bfloat16().float()
+
+
+def maxabs(a, b):
+    return (torch.as_tensor(a).float().cpu() - torch.as_tensor(b).float().cpu()).abs().max().item()
+
+
+def tiny_case(guidance_embed=False, depth=2, singles=2, C=3, T=8, side=256):
+    p = tiny_params(guidance_embed=guidance_embed, depth=depth, depth_single_blocks=singles)
+    sd = {k: bf(v) for k, v in synthetic_state_dict(p, seed=1).items()}
+    inp = {k: (bf(v) if v.is_floating_point() else v)
+           for k, v in synthetic_inputs(p, side, side, n_txt=T, n_concepts=C, seed=2).items()}
+    return p, sd, inp
+
+
+def run_hip(p, sd, inp, t, guidance=None, **kw):
+    m = HipFluxDiT(p, DEV)
+    m.load_state_dict(sd)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    img = O.patchify(inp["latent"]).to(DEV)
+    return m, m(img=img, img_ids=d["img_ids"], txt=d["txt"], txt_ids=d["txt_ids"], concepts=d["concepts"],
+                concept_ids=d["concept_ids"], concept_vec=d["concept_vec"], y=d["vec"],
+                timesteps=torch.tensor([t], device=DEV),
+                guidance=None if guidance is None else torch.tensor([guidance], device=DEV), **kw)
+
+
+@pytest.mark.parametrize("guidance_embed", [False, True])
+def test_tiny_model_matches_oracle(guidance_embed):
+    p, sd, inp = tiny_case(guidance_embed)
+    t, g = 0.75, 3.5
+    pred_o, d_o = O.dit_forward(sd, p, O.patchify(inp["latent"]), inp["img_ids"], inp["txt"], inp["txt_ids"],
+                                inp["concepts"], inp["concept_ids"], inp["concept_vec"], torch.tensor([t]),
+                                inp["vec"], torch.tensor([g]))
+    _, (pred, d) = run_hip(p, sd, inp, t, g)
+    assert pred.shape == pred_o.shape and pred.dtype == torch.bfloat16
+    for k in DICT_KEYS:
+        assert tuple(d[k].shape) == tuple(d_o[k].shape), k
+        scale = d_o[k].abs().max().item()
+        assert maxabs(d[k], d_o[k]) < 2e-2 * max(scale, 1.0), (k, maxabs(d[k], d_o[k]), scale)
+    assert maxabs(pred, pred_o) < 3e-2 * max(pred_o.abs().max().item(), 1.0)
+    # heat maps from the HIP vectors through the HIP reduction vs the oracle's fp32 maps
+    st = {k: v[None] for k, v in d.items()}
+    st_o = {k: v[None] for k, v in d_o.items()}
+    hm = compute_heatmaps_from_vectors(st["output_space_image_vectors"], st["output_space_concept_vectors"],
+                                       layer_indices=[0, 1], timesteps=[0])
+    hm_o = O.compute_heatmaps(st_o["output_space_image_vectors"], st_o["output_space_concept_vectors"], [0, 1], [0])
+    assert hm.shape == hm_o.shape == (1, 3, 16, 16)
+    # two chained blocks (layer 1 sees layer 0's bf16 residual stream, not teacher-forced): 3e-3
+    assert maxabs(hm, hm_o) < 3e-3
+
+
+def test_tiny_stop_after_multimodal_and_fused_heatmaps():
+    p, sd, inp = tiny_case()
+    _, d_o = O.dit_forward(sd, p, O.patchify(inp["latent"]), inp["img_ids"], inp["txt"], inp["txt_ids"],
+                           inp["concepts"], inp["concept_ids"], inp["concept_vec"], torch.tensor([0.5]),
+                           inp["concept_vec"], stop_after_multimodal_attentions=True)
+    C, Lp = 3, 256
+    req = HeatmapRequest((1,), 1.0, torch.zeros(C, Lp, device=DEV), torch.zeros(C, Lp, device=DEV))
+    m = HipFluxDiT(p, DEV)
+    m.load_state_dict(sd)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    pred, dd = m(img=O.patchify(inp["latent"]).to(DEV), img_ids=d["img_ids"], txt=d["txt"], txt_ids=d["txt_ids"],
+                 concepts=d["concepts"], concept_ids=d["concept_ids"], concept_vec=d["concept_vec"],
+                 y=d["concept_vec"], timesteps=torch.tensor([0.5], device=DEV),
+                 stop_after_multimodal_attentions=True, return_vectors=False, heatmaps=req)
+    assert pred is None and dd == {}
+    st = {k: v[None] for k, v in d_o.items()}
+    ho = O.compute_heatmaps(st["output_space_image_vectors"], st["output_space_concept_vectors"], [1], [0])
+    hc = O.compute_heatmaps(st["cross_attention_image_vectors"], st["cross_attention_concept_vectors"], [1], [0])
+    assert maxabs(req.out_space.view(1, C, 16, 16), ho) < 3e-3  # layer 1 of a chained pair (see above)
+    assert maxabs(req.cross_space.view(1, C, 16, 16), hc) < 5e-3  # cross logits have std > 1: bf16 q rounding
+
+
+def test_tiny_ablation_branches():
+    p, sd, inp = tiny_case(depth=1, singles=0)
+    for cross in (True, False):
+        for self_ in (True, False):
+            jak = {"concept_cross_attention": cross, "concept_self_attention": self_}
+            _, d_o = O.dit_forward(sd, p, O.patchify(inp["latent"]), inp["img_ids"], inp["txt"], inp["txt_ids"],
+                                   inp["concepts"], inp["concept_ids"], inp["concept_vec"], torch.tensor([0.5]),
+                                   inp["vec"], stop_after_multimodal_attentions=True, joint_attention_kwargs=jak)
+            _, (_, d) = run_hip(p, sd, inp, 0.5, stop_after_multimodal_attentions=True, joint_attention_kwargs=jak)
+            for k in ("output_space_concept_vectors", "cross_attention_concept_vectors"):
+                assert maxabs(d[k], d_o[k]) < 2e-2 * max(1.0, d_o[k].abs().max().item()), (jak, k)
+
+
+def test_argument_errors_match_reference():
+    p, sd, inp = tiny_case(guidance_embed=True, depth=1, singles=0)
+    m = HipFluxDiT(p, DEV)
+    m.load_state_dict(sd)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    img = O.patchify(inp["latent"]).to(DEV)
+    kw = dict(img_ids=d["img_ids"], txt=d["txt"], txt_ids=d["txt_ids"], concepts=d["concepts"],
+              concept_ids=d["concept_ids"], concept_vec=d["concept_vec"], y=d["vec"],
+              timesteps=torch.tensor([0.5], device=DEV))
+    with pytest.raises(ValueError):  # modified_flux_dit.py:102
+        m(img=img, guidance=None, **kw)
+    with pytest.raises(ValueError):  # modified_flux_dit.py:94-95
+        m(img=img[0], guidance=torch.tensor([1.0]), **kw)
+    with pytest.raises(ValueError):
+        tiny_params(num_heads=3)  # hidden % heads
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"nope": torch.zeros(1)})
+
+
+def _full_block_model(prefix_kind):
+    """A HipFluxDiT holding ONE full-size block (H=3072) with the golden case's weights."""
+    from oracle.full_block_case import full_block_inputs
+    p = FluxParams(depth=1 if prefix_kind == "double" else 0, depth_single_blocks=0 if prefix_kind == "double" else 1)
+    case = full_block_inputs(p)
+    m = HipFluxDiT(p, DEV)
+    pref = "double_blocks.0." if prefix_kind == "double" else "single_blocks.0."
+    sd = synthetic_state_dict(p, seed=0, prefix=pref)
+    m.load_state_dict(sd, strict=False)
+    L, T, C = 4096, 256, 4
+    m._workspace(L, T, C)
+    m._rope_table(case["img_ids"], case["txt_ids"], case["concept_ids"], C, T)
+    m.X[:C].copy_(case["concepts"][0])
+    m.X[C:C + T].copy_(case["txt"][0])
+    m.X[C + T:].copy_(case["img"][0])
+    m.VEC[0].copy_(case["vec"][0])
+    m.VEC[1].copy_(case["concept_vec"][0])
+    m._modulations()
+    return m, case, (L, T, C)
+
+
+def test_full_size_double_block_vs_reference_golden(golden):
+    """BASELINE.json configs[1] geometry, one block, teacher-forced inputs: the reference's own
+    outputs (tests/golden/block_full.npz) are the expected values."""
+    g = golden("block_full.npz")
+    m, case, (L, T, C) = _full_block_model("double")
+    out = {k: [] for k in DICT_KEYS}
+    req = HeatmapRequest((0,), 1.0, torch.zeros(C, L, device=DEV), torch.zeros(C, L, device=DEV))
+    m._double_block(0, C, T, L, None, out, True, req)
+    torch.cuda.synchronize()
+    rows = torch.from_numpy(g["sample_rows"]).to(DEV)
+    CT = C + T
+    # attention outputs (pre-proj): SURVEY measured 1.5e-3 bf16-vs-fp32 on these
+    assert maxabs(m.ATT[:C], g["concept_attn"][0]) < 4e-3
+    assert maxabs(m.ATT[CT:][rows], g["img_attn_rows"]) < 8e-3
+    # normalised pre-RoPE q (|q| up to ~0.6 with the synthetic 0.15 scale)
+    cq = m.QPRE[:C].view(C, 24, 128).permute(1, 0, 2)
+    assert maxabs(cq, g["concept_q"][0]) < 4e-3
+    iq = m.QPRE[CT:].view(L, 24, 128).permute(1, 0, 2)[:, rows]
+    assert maxabs(iq, g["img_q_rows"]) < 4e-3
+    # pre-softmax logits pin the reduction itself (random-init maps are nearly uniform)
+    ops.heatmap_logits(m.ATT[CT:], m.ATT32[:C], m.LOGITS[:C])
+    ref_lo = torch.from_numpy(g["logits_output_space"][0])
+    assert maxabs(m.LOGITS[:C], ref_lo) < 2e-2 * max(1.0, ref_lo.abs().max().item())
+    # heat maps: <= 1e-3 max-abs (output space), the north-star tolerance
+    hm = req.out_space.view(C, 64, 64)
+    assert maxabs(hm, g["heatmap_output_space"][0]) < 1e-3
+    assert abs(hm.sum(0) - 1).max().item() < 1e-5
+    # cross-attention-space maps are ill-conditioned (logit std ~3 even with the scaled synthetic
+    # norms): stated bound 2e-2 max-abs, and the per-patch winner must agree almost everywhere
+    cm = req.cross_space.view(C, 64, 64).cpu()
+    ref_cm = torch.from_numpy(g["heatmap_cross_attention"][0])
+    assert maxabs(cm, ref_cm) < 2e-2
+    agree = (cm.argmax(0) == ref_cm.argmax(0)).float().mean().item()
+    assert agree > 0.99, agree
+    # residual streams after the block (values O(1..5); SURVEY: 2.7e-2 bf16-vs-fp32)
+    assert maxabs(m.X[CT:][rows], g["img_out_rows"]) < 6e-2
+    assert maxabs(m.X[C:CT][::8], g["txt_out"]) < 6e-2
+    assert maxabs(m.X[:C], g["concepts_out"][0]) < 6e-2
+    # dict capture shapes = the reference's (modified_double_stream_block.py:185-191)
+    assert tuple(out["output_space_image_vectors"][0].shape) == (1, L, 3072)
+    assert tuple(out["cross_attention_image_vectors"][0].shape) == (1, 24, L, 128)
+
+
+def test_full_size_single_block_vs_reference_golden(golden):
+    g = golden("single_full.npz")
+    m, case, (L, T, C) = _full_block_model("single")
+    m._single_block(0, C, T, L)
+    rows = torch.from_numpy(g["sample_rows"]).to(DEV)
+    assert maxabs(m.X[C:][rows], g["out_rows"]) < 6e-2
