@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: concept heat maps per second on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one generate_image-equivalent call of the hot path on synthetic inputs already
+resident in HBM: flux-schnell geometry, 1024x1024 (4096 image tokens), 256 text tokens, 4 concepts,
+4 sequential diffusion steps, heat maps of double blocks 15..18 in both spaces
+(BASELINE.json configs[1]; random-init weights, seeded synthetic latents/embeddings).
+N > 1: one process per GPU (torch.distributed.run), a full weight replica per GPU, work items
+round-robin over ranks, ONE RCCL all_gather of the (C,64,64) fp32 maps at the end -- weak scaling.
+Rank 0 prints ONE JSON line.  `value` = heat maps produced by all ranks / wall time (max over ranks).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+# ---- algorithmic FLOPs of the path: GEMM 2MNK, attention 4*Nq*Nk*D*heads,
+#      concept attention counted for the C query rows only, heat map 2*C*L*H per space
+def step_flops(p, L, T, C):
+    H, MLP, NH, D = p.hidden_size, p.mlp_hidden, p.num_heads, p.head_dim
+    lin_tok = 2 * H * 3 * H + 2 * H * H + 4 * H * MLP
+    dbl = lin_tok * (L + T + C) + 4 * (L + T) ** 2 * D * NH + 4 * C * (C + L) * D * NH + 3 * 2 * H * 6 * H
+    sgl = lin_tok * (L + T) + 4 * (L + T) ** 2 * D * NH + 2 * H * 3 * H
+    io = 2 * L * p.in_channels * H * 2 + 2 * (T + C) * p.context_in_dim * H
+    return p.depth * dbl + p.depth_single_blocks * sgl + io
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline(p, L, T, C, steps_per_call, n_layers_double, n_layers_single):
+    """The CPU oracle (fp32 restatement of the reference, oracle/flux_oracle.py) timed on this
+    host's cores on a bounded sample: one full-size double block + one single block, extrapolated
+    to the 19+38 blocks x 4 steps of one call.  Reported next to the GPU number, never mixed in."""
+    from conceptattention_amd.weights import synthetic_state_dict
+    from oracle import flux_oracle as O
+    from oracle.full_block_case import full_block_inputs
+    # the GPU box grants a 1-GPU job a 16-core share of its host (more threads only oversubscribe)
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    case = full_block_inputs(p, T=T, C=C)
+    sd = synthetic_state_dict(p, seed=0, prefix="double_blocks.0.")
+    sd.update(synthetic_state_dict(p, seed=0, prefix="single_blocks.0."))
+    rope_ti = O.rope_cos_sin(torch.cat((case["txt_ids"][0], case["img_ids"][0])), p.axes_dim, p.theta)
+    rope_ci = O.rope_cos_sin(torch.cat((case["concept_ids"][0], case["img_ids"][0])), p.axes_dim, p.theta)
+    x = torch.cat((case["txt"], case["img"]), 1)
+
+    def dbl():
+        return O.double_block(sd, "double_blocks.0.", p.num_heads, case["img"], case["txt"], case["vec"], rope_ti,
+                              case["concepts"], case["concept_vec"], rope_ci)
+
+    def sgl():
+        return O.single_block(sd, "single_blocks.0.", p.num_heads, x, case["vec"], rope_ti)
+
+    with torch.no_grad():
+        dbl(), sgl()  # warm
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dbl()
+        td = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sgl()
+        ts = (time.perf_counter() - t0) / reps
+    call_s = steps_per_call * (n_layers_double * td + n_layers_single * ts)
+    return {"value": C / call_s, "unit": "concept-heatmaps/s", "cores": cores, "kind": "port",
+            "sample": (f"fp32 oracle, 1 double block ({td:.2f} s) + 1 single block ({ts:.2f} s) at L={L} T={T} C={C}, "
+                       f"{reps} reps each after 1 warm-up, extrapolated x({n_layers_double},{n_layers_single}) "
+                       f"x{steps_per_call} steps = {call_s:.0f} s per call"),
+            "seconds_per_call": call_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="flux-schnell")
+    ap.add_argument("--concepts", type=int, default=4)
+    ap.add_argument("--diffusion-steps", type=int, default=4)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the per-launch HIP-event timing of the GEMM kernel (roofline.achieved then "
+                         "comes from whole-path FLOPs / wall time)")
+    args = ap.parse_args()
+
+    from conceptattention_amd import distributed as D
+    from conceptattention_amd import ops
+    from conceptattention_amd import _lib as L
+    from conceptattention_amd.params import T5_TOKENS, configs
+    from conceptattention_amd.pipeline import ConceptAttentionFluxPipeline
+    from conceptattention_amd.weights import synthetic_inputs
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    if L.load().ca_check_device() != 0:
+        raise SystemExit(L.load().ca_last_error().decode())
+
+    p = configs[args.model]
+    C, T = args.concepts, T5_TOKENS[args.model]
+    Lp = (args.size // 16) ** 2
+    pipe = ConceptAttentionFluxPipeline(args.model, device=dev, weights="synthetic", weight_seed=0)
+    layer_indices = list(range(15, 19))
+    n_items = world * (args.warmup + args.steps)
+
+    # every work item's inputs are generated and made resident in HBM before timing
+    def item_inputs(j):
+        inp = synthetic_inputs(p, args.size, args.size, T, C, seed=1000 + j, device="cpu", dtype=torch.bfloat16)
+        return {k: inp[k].to(dev) for k in ("latent", "txt", "vec", "concepts")}
+
+    my_items = D.shard_items(n_items, rank, world)
+    warm_items, timed_items = my_items[: args.warmup], my_items[args.warmup:]
+    inputs = {j: item_inputs(j) for j in my_items}
+
+    def run_item(j):
+        i = inputs[j]
+        _, hm, cm = pipe.generate_on_device(i["latent"], i["txt"], i["vec"], i["concepts"],
+                                            layer_indices=layer_indices, num_inference_steps=args.diffusion_steps,
+                                            guidance=0.0)
+        return torch.stack((hm[0], cm[0]))  # [2, C, side, side]
+
+    for j in warm_items:
+        run_item(j)
+
+    # ---- per-launch timing of the GEMM kernel with HIP events on the launch stream
+    records = []
+    if not args.no_kernel_timing:
+        def hook(arr, tile, launch):
+            fl = sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(len(arr)))
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            launch()
+            e.record()
+            records.append((tile, fl, s, e))
+        ops.set_gemm_hook(hook)
+
+    torch.cuda.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    local_maps = [run_item(j) for j in timed_items]
+    local_maps = torch.stack(local_maps) if local_maps else torch.zeros(0, 2, C, args.size // 16, args.size // 16, device=dev)
+    # the one collective of the job: gather the small fp32 maps of all ranks (RCCL over xGMI)
+    timed_global = sorted(j for r in range(world) for j in D.shard_items(n_items, r, world)[args.warmup:])
+    if world > 1:
+        per = len(timed_items)
+        out = torch.empty((world, per) + tuple(local_maps.shape[1:]), device=dev)
+        torch.distributed.all_gather_into_tensor(out.view(world * per, *local_maps.shape[1:]), local_maps)
+        all_maps = out.view(world * per, *local_maps.shape[1:])
+    else:
+        all_maps = local_maps
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, dev)
+    ops.set_gemm_hook(None)
+
+    calls = len(timed_global)
+    maps_ok = bool(torch.isfinite(all_maps).all().item()) and abs(all_maps[:, 0].sum(1).mean().item() - 1.0) < 1e-3
+
+    if rank == 0:
+        flops_call = args.diffusion_steps * step_flops(p, Lp, T, C) + \
+            len(layer_indices) * args.diffusion_steps * 2 * (2 * C * Lp * p.hidden_size)
+        path_tflops = flops_call * calls / elapsed / 1e12 / world  # per GPU
+        roof = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+        if records:
+            torch.cuda.synchronize()
+            by_tile = {}
+            for tile, fl, s, e in records:
+                d = by_tile.setdefault(tile, [0.0, 0.0, 0])
+                d[0] += fl
+                d[1] += s.elapsed_time(e) * 1e-3
+                d[2] += 1
+            tile, (fl, sec, n) = max(by_tile.items(), key=lambda kv: kv[1][1])
+            names = {1: "ca_gemm_kernel<8,4> (256x256x64)", 2: "ca_gemm_kernel<8,3> (256x192x64)",
+                     3: "ca_gemm_kernel<8,2> (256x128x64)", 4: "ca_gemm_kernel<8,1> (256x64x64)"}
+            roof.update(kernel=names.get(tile, str(tile)), launches=n, avg_launch_us=sec / n * 1e6,
+                        flops_per_launch=fl / n, achieved=fl / sec / 1e12,
+                        share_of_wall=sec / (elapsed * 1.0))
+        else:
+            roof.update(kernel="whole path", achieved=path_tflops)
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["path_achieved"] = path_tflops
+        roof["path_frac"] = path_tflops / MFMA_BF16_PEAK_TFLOPS
+        res = {
+            "metric": "concept-heatmaps/sec (1024x1024, 4 concepts, 4 steps)",
+            "value": calls * C / elapsed,
+            "unit": "concept-heatmaps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} bf16 {args.size}x{args.size}, {C} concepts, "
+                                   f"{args.diffusion_steps} diffusion steps, {T} text tokens "
+                                   "(generate_image-equivalent call; random-init weights, synthetic latents/embeddings)",
+                       "calls_per_step_per_gpu": 1, "heatmap_layers": layer_indices,
+                       "tflop_per_call": flops_call / 1e12, "parallelism": f"replica x{world} (work items round-robin)"},
+            "calls_per_s": calls / elapsed,
+            "outputs_finite_and_normalised": maps_ok,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(p, Lp, T, C, args.diffusion_steps, p.depth, p.depth_single_blocks)
+        print(json.dumps(res), flush=True)
+    D.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

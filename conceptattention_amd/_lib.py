@@ -48,6 +48,7 @@ SIGNATURES = {
     "ca_last_error": (C.c_char_p, []),
     "ca_check_device": (C.c_int, []),
     "ca_gemm_bf16": (C.c_int, [C.POINTER(GemmProblem), C.c_int32, C.c_int32, C.c_void_p]),
+    "ca_gemm_auto_tile": (C.c_int, [C.POINTER(GemmProblem), C.c_int32]),
     "ca_attn_fwd_bf16": (C.c_int, [C.POINTER(AttnProblem), C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "ca_ln_modulate_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),

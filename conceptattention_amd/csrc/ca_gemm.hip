@@ -299,6 +299,19 @@ int auto_tile(const ca_gemm_problem *p, int n) {
 
 }  // namespace
 
+extern "C" int ca_gemm_auto_tile(const ca_gemm_problem *problems, int32_t n_problems) {
+  if (!problems || n_problems < 1 || n_problems > CA_GEMM_MAX_PROBLEMS) {
+    ca_set_error("ca_gemm_auto_tile: n_problems=%d out of range", n_problems);
+    return CA_ERR_ARG;
+  }
+  const int t = auto_tile(problems, n_problems);
+  if (!t) {
+    ca_set_error("ca_gemm_auto_tile: no tile width divides N (need N %% 64 == 0)");
+    return CA_ERR_ARG;
+  }
+  return t;
+}
+
 extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
                             ca_stream_t stream) {
   if (!problems || n_problems < 1 || n_problems > CA_GEMM_MAX_PROBLEMS) {

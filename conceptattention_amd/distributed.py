@@ -1,0 +1,82 @@
+"""Work-item sharding over the GPUs of one node and the final heat-map gather.
+
+The reference has no multi-GPU layer; its own multi-GPU use is one process per
+`--device cuda:N`.  The path shards across *independent work items* only (the
+timesteps inside one generate_image call are a sequential recurrence and the concepts are coupled
+through the joint softmax, so neither can be split exactly): item j runs on rank j % world_size
+with a full weight replica per GPU (23.8 GB of 288 GB), and the only collective is one RCCL
+all_gather of the small (C,h,w) fp32 heat maps at the end.  Contract: the N-GPU result equals the
+1-GPU result item for item (same kernels, same seeds), returned in item order.
+"""
+from __future__ import annotations
+
+import os
+from typing import Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """One process per GPU as launched by torch.distributed.run: reads RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*.  Returns (rank, world, local_rank).  backend "nccl" is RCCL on ROCm."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_items(n_items: int, rank: int, world: int) -> list[int]:
+    """Round-robin: rank r owns items r, r+world, ...  (SURVEY.md §8e partitioning 1)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return list(range(rank, n_items, world))
+
+
+def gather_heatmaps(local_maps: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:
+    """local_maps [n_local, ...] for items shard_items(n_items, rank, world) -> [n_items, ...] in item
+    order on every rank.  One all_gather of the padded per-rank block (ranks may own one item fewer)."""
+    mine = shard_items(n_items, rank, world)
+    if local_maps.shape[0] != len(mine):
+        raise ValueError(f"rank {rank} holds {local_maps.shape[0]} maps but owns {len(mine)} items")
+    if world == 1:
+        return local_maps
+    per = (n_items + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local_maps.shape[1:]), dtype=local_maps.dtype, device=local_maps.device)
+    pad[: len(mine)] = local_maps
+    out = torch.empty((world, per) + tuple(local_maps.shape[1:]), dtype=local_maps.dtype, device=local_maps.device)
+    dist.all_gather_into_tensor(out.view(world * per, *local_maps.shape[1:]), pad)
+    full = torch.empty((n_items,) + tuple(local_maps.shape[1:]), dtype=local_maps.dtype, device=local_maps.device)
+    for r in range(world):
+        idx = shard_items(n_items, r, world)
+        full[idx] = out[r, : len(idx)]
+    return full
+
+
+def allreduce_sum_(acc: torch.Tensor) -> torch.Tensor:
+    """Partial sums of a sharded noise-level sweep (SURVEY.md §8e partitioning 2): one all_reduce of
+    the fp32 (C, patches) accumulator."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    return acc
+
+
+def max_over_ranks(value: float, device) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -74,7 +74,23 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
             if g.out2 is None:
                 raise ValueError(f"gemm[{i}]: SPLIT_GELU needs out2")
             p.out2, p.ld2, p.n_split = _chk(g.out2, torch.bfloat16, "out2").data_ptr(), g.out2.stride(0), g.n_split
+    if _gemm_hook is not None:
+        if tile == L.TILE_AUTO:
+            tile = lib.ca_gemm_auto_tile(arr, len(problems))
+            if tile <= 0:
+                L.check(tile, "ca_gemm_auto_tile")
+        _gemm_hook(arr, tile, lambda: L.check(lib.ca_gemm_bf16(arr, len(problems), tile, _stream()), "ca_gemm_bf16"))
+        return
     L.check(lib.ca_gemm_bf16(arr, len(problems), tile, _stream()), "ca_gemm_bf16")
+
+
+# Optional instrumentation used by bench.py: hook(problem_array, tile, launch) must call launch().
+_gemm_hook = None
+
+
+def set_gemm_hook(hook) -> None:
+    global _gemm_hook
+    _gemm_hook = hook
 
 
 def linear(a, w, bias, out=None, epilogue=L.EPI_BIAS, tile=L.TILE_AUTO, **kw):

@@ -136,43 +136,53 @@ class ConceptAttentionFluxPipeline:
         if timesteps is None:
             timesteps = list(range(num_inference_steps))
         x = latent if latent is not None else sampling.get_noise(1, height, width, self.device, torch.bfloat16, seed)
-        x = x.to(self.device, torch.bfloat16)
-        schedule = sampling.get_schedule(num_inference_steps, x.shape[-1] * x.shape[-2] // 4,
-                                         shift=(not self.is_schnell))
         txt, vec, con, con_ids, con_vec = self._embed(prompt, concepts)
-        inp = sampling.prepare_from_embeddings(x, txt, vec)
-        C, n_patches = con.shape[1], inp["img"].shape[1]
-        if fused:
-            ts = [int(t) for t in timesteps]
-            req = HeatmapRequest(tuple(int(l) for l in layer_indices), 1.0 / (len(ts) * len(layer_indices)),
-                                 torch.zeros(C, n_patches, device=self.device),
-                                 torch.zeros(C, n_patches, device=self.device))
-            # repeated indices weigh a (step, layer) pair repeatedly, as indexing does in the reference
-            img = None
-            counts = {t: ts.count(t) for t in set(ts)}
-            lcounts = {l: list(layer_indices).count(l) for l in set(layer_indices)}
-            if any(v > 1 for v in counts.values()) or any(v > 1 for v in lcounts.values()):
-                fused = False
-            else:
-                img, _, _ = sampling.denoise(self.model, **inp, timesteps=schedule, guidance=guidance,
-                                             concepts=con, concept_ids=con_ids, concept_vec=con_vec,
-                                             return_intermediate_images=False, return_vectors=False,
-                                             heatmaps=req, heatmap_timesteps=ts)
-                side = int(round(n_patches ** 0.5))
-                concept_heatmaps = req.out_space.view(1, C, side, side)
-                cross_attention_maps = req.cross_space.view(1, C, side, side)
-        if not fused:
-            img, _, d = sampling.denoise(self.model, **inp, timesteps=schedule, guidance=guidance, concepts=con,
-                                         concept_ids=con_ids, concept_vec=con_vec,
-                                         return_intermediate_images=False)
-            cross_attention_maps = compute_heatmaps_from_vectors(
-                d["cross_attention_image_vectors"], d["cross_attention_concept_vectors"],
-                layer_indices=layer_indices, timesteps=timesteps, softmax=softmax, attention_norm=attention_norm)
-            concept_heatmaps = compute_heatmaps_from_vectors(
-                d["output_space_image_vectors"], d["output_space_concept_vectors"],
-                layer_indices=layer_indices, timesteps=timesteps, softmax=softmax, attention_norm=attention_norm)
+        img, concept_heatmaps, cross_attention_maps = self.generate_on_device(
+            x, txt, vec, con, layer_indices=layer_indices, num_inference_steps=num_inference_steps,
+            guidance=guidance, timesteps=timesteps, fused=fused)
         image = self._decode(img, height, width)
         return self._finish(image, concept_heatmaps, cross_attention_maps, return_pil_heatmaps, cmap)
+
+    @torch.no_grad()
+    def generate_on_device(self, latent, txt, vec, concept_embeddings, layer_indices=list(range(15, 19)),
+                           num_inference_steps: int = 4, guidance: float = 0.0, timesteps=None, fused: bool = True):
+        """The device-resident core of generate_image: latent (1,16,h/8,w/8), txt (1,T,4096),
+        vec (1,768), concept_embeddings (1,C,4096) already in HBM -> (final latent tokens,
+        concept heat maps fp32 [1,C,side,side], cross-attention maps fp32 [1,C,side,side]) on the
+        device, no host synchronisation."""
+        if timesteps is None:
+            timesteps = list(range(num_inference_steps))
+        x = latent.to(self.device, torch.bfloat16)
+        schedule = sampling.get_schedule(num_inference_steps, x.shape[-1] * x.shape[-2] // 4,
+                                         shift=(not self.is_schnell))
+        con, con_ids, con_vec = sampling.concept_inputs(concept_embeddings, vec)
+        inp = sampling.prepare_from_embeddings(x, txt, vec)
+        C, n_patches = con.shape[1], inp["img"].shape[1]
+        ts = [int(t) for t in timesteps]
+        ls = [int(l) for l in layer_indices]
+        # repeated indices weigh a (step, layer) pair repeatedly in the reference's fancy indexing
+        # (concept_attention_pipeline.py:76-77); the fused accumulation covers distinct pairs only
+        if fused and (len(set(ts)) != len(ts) or len(set(ls)) != len(ls)):
+            fused = False
+        if fused:
+            req = HeatmapRequest(tuple(ls), 1.0 / (len(ts) * len(ls)),
+                                 torch.zeros(C, n_patches, device=self.device),
+                                 torch.zeros(C, n_patches, device=self.device))
+            img, _, _ = sampling.denoise(self.model, **inp, timesteps=schedule, guidance=guidance,
+                                         concepts=con, concept_ids=con_ids, concept_vec=con_vec,
+                                         return_intermediate_images=False, return_vectors=False,
+                                         heatmaps=req, heatmap_timesteps=ts)
+            side = int(round(n_patches ** 0.5))
+            return img, req.out_space.view(1, C, side, side), req.cross_space.view(1, C, side, side)
+        img, _, d = sampling.denoise(self.model, **inp, timesteps=schedule, guidance=guidance, concepts=con,
+                                     concept_ids=con_ids, concept_vec=con_vec, return_intermediate_images=False)
+        cross_attention_maps = compute_heatmaps_from_vectors(
+            d["cross_attention_image_vectors"], d["cross_attention_concept_vectors"],
+            layer_indices=layer_indices, timesteps=timesteps)
+        concept_heatmaps = compute_heatmaps_from_vectors(
+            d["output_space_image_vectors"], d["output_space_concept_vectors"],
+            layer_indices=layer_indices, timesteps=timesteps)
+        return img, concept_heatmaps, cross_attention_maps
 
     # ------------------------------------------------------------------ encode_image (:204-357)
     @torch.no_grad()

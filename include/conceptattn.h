@@ -83,6 +83,8 @@ typedef struct {
 } ca_gemm_problem;
 
 int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile, ca_stream_t stream);
+/* The CA_TILE_* value CA_TILE_AUTO resolves to for these problems (> 0), or CA_ERR_ARG. No launch. */
+int ca_gemm_auto_tile(const ca_gemm_problem *problems, int32_t n_problems);
 
 /* ------------------------------------------------------------------------------------------
  * Flash attention forward, head_dim 128, no mask:  out = softmax(q k^T * scale) v  per head.
