@@ -1,0 +1,86 @@
+"""Pipeline-level behaviour on the GPU: public API surface, fused vs stacked heat maps, encode path,
+the reference's heat-map known answers through the HIP reduction."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conceptattention_amd import ConceptAttentionFluxPipeline  # noqa: E402
+from conceptattention_amd.heatmaps import compute_heatmaps_from_vectors  # noqa: E402
+from conceptattention_amd.params import tiny_params  # noqa: E402
+from oracle import flux_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    return ConceptAttentionFluxPipeline("flux-schnell", device=DEV, weights="synthetic", params=tiny_params(),
+                                        n_text_tokens=8)
+
+
+def test_generate_image_api_and_fused_equals_stacked(pipe):
+    concepts = ["cat", "grass", "sky"]
+    kw = dict(prompt="A cat in a park", concepts=concepts, width=256, height=256, layer_indices=[0, 1],
+              num_inference_steps=2, seed=3, return_pil_heatmaps=False)
+    a = pipe.generate_image(**kw)
+    b = pipe.generate_image(fused=False, **kw)
+    assert a.concept_heatmaps.shape == (3, 16, 16) and a.cross_attention_maps.shape == (3, 16, 16)
+    assert a.image.shape == (16, 32, 32)  # no autoencoder injected: the unpacked latent
+    assert np.abs(a.concept_heatmaps.sum(0) - 1).max() < 1e-5
+    # same kernels, same order of operations except the concept rows' fp32 copy in the fused path
+    assert np.abs(a.concept_heatmaps - b.concept_heatmaps).max() < 2e-3
+    assert np.abs(a.cross_attention_maps - b.cross_attention_maps).max() < 1e-6
+    assert np.array_equal(a.image, b.image)
+    c = pipe.generate_image(**{**kw, "return_pil_heatmaps": True})
+    assert len(c.concept_heatmaps) == 3 and c.concept_heatmaps[0].size == (16, 16)
+    # determinism: same seed -> identical maps
+    a2 = pipe.generate_image(**kw)
+    assert np.array_equal(a.concept_heatmaps, a2.concept_heatmaps)
+    # repeated timestep indices (fancy-index semantics of the reference) route through the stacked path
+    d = pipe.generate_image(**{**kw, "timesteps": [1, 1]})
+    e = pipe.generate_image(**{**kw, "timesteps": [1]})
+    assert np.abs(d.concept_heatmaps - e.concept_heatmaps).max() < 2e-3
+
+
+def test_generate_image_argument_checks(pipe):
+    with pytest.raises(AssertionError):
+        pipe.generate_image("p", ["a"], width=256, height=128)
+    with pytest.raises(AssertionError):
+        pipe.generate_image("p", ["a"], width=256, height=256, layer_indices=[7])
+    with pytest.raises(AssertionError):
+        pipe.generate_image("p", ["a"], width=256, height=256, return_cross_attention=True)
+    with pytest.raises(NotImplementedError):
+        pipe.generate_image("p", ["a"], width=256, height=256, layer_indices=[0], softmax=False)
+
+
+def test_encode_image_runs_double_blocks_only(pipe):
+    latent = torch.randn(1, 16, 32, 32, generator=torch.Generator().manual_seed(0))
+    out = pipe.encode_image(latent, ["dragon", "rock"], prompt="A dragon", width=256, height=256,
+                            layer_indices=[0, 1], num_samples=2, return_pil_heatmaps=False)
+    assert out.concept_heatmaps.shape == (2, 16, 16)
+    assert np.abs(out.concept_heatmaps.sum(0) - 1).max() < 1e-5
+    with pytest.raises(ValueError):
+        pipe.encode_image(object(), ["x"], width=256, height=256, layer_indices=[0])
+
+
+def test_heatmap_known_answers_through_hip(golden):
+    g = golden("heatmap_kat.npz")
+    iv = torch.from_numpy(g["iv"]).float().bfloat16()
+    cv = torch.from_numpy(g["cv"]).float().bfloat16()
+    ref = O.compute_heatmaps(iv.float(), cv.float(), [1, 3, 4], [0, 2])  # oracle on the bf16-rounded inputs
+    out = compute_heatmaps_from_vectors(iv.to(DEV), cv.to(DEV), layer_indices=[1, 3, 4], timesteps=[0, 2])
+    assert out.shape == (1, 4, 64, 64)
+    assert (out.cpu() - ref).abs().max() < 1e-5
+    # and within bf16 input rounding of the reference's own fp32 answer
+    assert (out.cpu() - torch.from_numpy(g["out_a"])).abs().max() < 2e-2
+    iv6 = torch.from_numpy(g["iv6"]).float().bfloat16()
+    cv6 = torch.from_numpy(g["cv6"]).float().bfloat16()
+    ref6 = O.compute_heatmaps(iv6.float(), cv6.float(), [0, 1], [0, 1])
+    out6 = compute_heatmaps_from_vectors(iv6.to(DEV), cv6.to(DEV), layer_indices=[0, 1], timesteps=[0, 1])
+    assert (out6.cpu() - ref6).abs().max() < 1e-5
+    refn = O.compute_heatmaps(iv.float(), cv.float(), [2], [1], normalize_concepts=True)
+    outn = compute_heatmaps_from_vectors(iv.to(DEV), cv.to(DEV), layer_indices=[2], timesteps=[1],
+                                         normalize_concepts=True)
+    assert (outn.cpu() - refn).abs().max() < 5e-3  # normalised concepts are re-rounded to bf16
