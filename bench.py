@@ -188,7 +188,9 @@ def main():
                 d[2] += 1
             tile, (fl, sec, n) = max(by_tile.items(), key=lambda kv: kv[1][1])
             names = {1: "ca_gemm_kernel<8,4> (256x256x64)", 2: "ca_gemm_kernel<8,3> (256x192x64)",
-                     3: "ca_gemm_kernel<8,2> (256x128x64)", 4: "ca_gemm_kernel<8,1> (256x64x64)"}
+                     3: "ca_gemm_kernel<8,2> (256x128x64)", 4: "ca_gemm_kernel<8,1> (256x64x64)",
+                     5: "ca_gemm_pp_kernel<2,2> (256x256x64 ping-pong)", 6: "ca_gemm_pp_kernel<1,1> (256x128x64 ping-pong)",
+                     7: "ca_gemm_pp_kernel<2,1> (256x192x64 ping-pong)"}
             roof.update(kernel=names.get(tile, str(tile)), launches=n, avg_launch_us=sec / n * 1e6,
                         flops_per_launch=fl / n, achieved=fl / sec / 1e12,
                         share_of_wall=sec / (elapsed * 1.0))

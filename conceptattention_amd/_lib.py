@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libconceptattn.so")
 CA_VERSION = 100
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x256, TILE_256x192, TILE_256x128, TILE_256x64 = 0, 1, 2, 3, 4
+TILE_PP_256x256, TILE_PP_256x128, TILE_PP_256x192 = 5, 6, 7
 MAX_SEGMENTS = 4
 GEMM_MAX_PROBLEMS = 2
 

@@ -16,6 +16,8 @@
 //  * several problems share one launch (image stream + text/concept stream of a double block),
 //    tile ids are remapped so that the 32 workgroups that share an XCD (same blockIdx % 8) work
 //    on an 8(M) x 4(N) patch of tiles and reuse each other's panels in that XCD's L2.
+#include <type_traits>
+
 #include "ca_common.h"
 
 namespace {
@@ -239,6 +241,329 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_kernel(const GemmLaunch L) {
   }
 }
 
+// =============================================================================================
+// Ping-pong variant (the fast path for BN = 256 / 128).
+//
+// The 8 waves form two groups of 4 (one wave of each group per SIMD).  A K tile is consumed in 4
+// phases, one C quadrant each:  (A-lo x W-lo), (A-lo x W-hi), (A-hi x W-hi), (A-hi x W-lo), where
+// lo/hi are the 128-row halves of the block's A tile and the BN/2-row halves of its W tile, and
+// every wave owns 64 rows of each A half and 16*NH rows of each W half.  Per phase a wave
+//   reads the fragments that phase introduces (ds_read_b128), issues the global_load_lds of ONE
+//   half tile of a later K tile, s_barrier, 16*NH MFMAs, counted s_waitcnt vmcnt, s_barrier.
+// Group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA segment while
+// the other one reads LDS / issues DMA: the matrix pipe never waits for ds_read latency, and the
+// DMA of 2-3 half tiles stays in flight across the barriers (no vmcnt(0) in the loop).
+// Hand-off rules (MI355X_MICROARCH.md, LDS-DMA visibility): a half tile staged in phase q is first
+// read in phase q+4 or later; every wave waits `vmcnt(cntA+cntW)` (all but the two youngest half
+// tiles) before the closing barrier of each phase, which retires everything staged <= q-2 in its
+// own group and, one barrier later, in the other group.  Restaging a buffer happens >= 3 phases
+// after its last ds_read.  K tiles past the end are staged from the clamped last tile into a
+// buffer nobody reads again, so the wait counts stay uniform without a loop tail.
+template <int NL, int NHI>  // 16-column fragments per wave in the lo / hi half of the W tile
+struct PPCfg {
+  static constexpr int BM = 256, BN = 64 * (NL + NHI), BK = 64, ROW_BYTES = 128;
+  static constexpr int A_HALF = 128 * ROW_BYTES;      // 16 KB
+  static constexpr int WL_BYTES = 64 * NL * ROW_BYTES;
+  static constexpr int WH_BYTES = 64 * NHI * ROW_BYTES;
+  static constexpr int OFF_AL = 0, OFF_AH = A_HALF, OFF_WL = 2 * A_HALF, OFF_WH = 2 * A_HALF + WL_BYTES;
+  static constexpr int BUF_BYTES = 2 * A_HALF + WL_BYTES + WH_BYTES;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+  static constexpr int CNT_A = 2;  // global_load_lds per thread per A half tile (W halves: NL, NHI)
+};
+
+template <int N>
+__device__ __forceinline__ void ca_wait_vmcnt() {
+  static_assert(N >= 0 && N <= 6, "unsupported vmcnt");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
+template <int NL, int NHI>
+__global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) {
+  using C = PPCfg<NL, NHI>;
+  constexpr int NT_ = NL + NHI;
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int nblk = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
+  int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int prob = (lid >= L.ntiles[0]) ? 1 : 0;
+  if (prob) lid -= L.ntiles[0];
+  const ca_gemm_problem &P = L.p[prob];
+  const int MT = L.mt[prob], NT = L.nt[prob];
+  const int grp = lid / (GROUP_M * NT);
+  const int first_m = grp * GROUP_M;
+  const int gm = min(GROUP_M, MT - first_m);
+  const int in_grp = lid - grp * GROUP_M * NT;
+  const int m0 = (first_m + in_grp % gm) * C::BM;
+  const int n0 = (in_grp / gm) * C::BN;
+  const int M = P.M;
+  const char *Ab = (const char *)P.A;
+  const char *Wb = (const char *)P.W;
+  const int nk = P.K / C::BK;
+
+  // ---- per-lane source offsets (bytes, k = 0) of the staging loads of each half tile
+  uint32_t offA[2][C::CNT_A], offWL[NL], offWH[NHI];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < C::CNT_A; ++i) {
+      const int rr = i * 64 + wave * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((rr >> 1) & 7);
+      const int row = min(m0 + h * 128 + rr, M - 1);
+      offA[h][i] = ((uint32_t)row * (uint32_t)P.lda + (uint32_t)c * 8u) * 2u;
+    }
+  auto w_src = [&](int rr, int nfrag, int nbase) {
+    // LDS row rr of a W half holds weight row nbase + perm(rr): within each wave's 16*nfrag rows the
+    // order is permuted so that a lane's accumulators are 4*nfrag contiguous output columns
+    const int c = (lane & 7) ^ ((rr >> 1) & 7);
+    const int wloc = rr % (16 * nfrag);
+    const int j = wloc >> 4, a = (wloc >> 2) & 3, b = wloc & 3;
+    const int n = nbase + (rr - wloc) + 4 * nfrag * a + 4 * j + b;
+    return ((uint32_t)n * (uint32_t)P.ldw + (uint32_t)c * 8u) * 2u;
+  };
+#pragma unroll
+  for (int i = 0; i < NL; ++i) offWL[i] = w_src(i * 64 + wave * 8 + (lane >> 3), NL, n0);
+#pragma unroll
+  for (int i = 0; i < NHI; ++i) offWH[i] = w_src(i * 64 + wave * 8 + (lane >> 3), NHI, n0 + 64 * NL);
+
+  auto stageA = [&](int buf, int h, int kt) {
+    const uint32_t kb = (uint32_t)min(kt, nk - 1) * (C::BK * 2);
+    char *base = smem + buf * C::BUF_BYTES + (h ? C::OFF_AH : C::OFF_AL) + wave * 8 * C::ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::CNT_A; ++i) ca_glds16(Ab + offA[h][i] + kb, base + i * 64 * C::ROW_BYTES);
+  };
+  auto stageWL = [&](int buf, int kt) {
+    const uint32_t kb = (uint32_t)min(kt, nk - 1) * (C::BK * 2);
+    char *base = smem + buf * C::BUF_BYTES + C::OFF_WL + wave * 8 * C::ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) ca_glds16(Wb + offWL[i] + kb, base + i * 64 * C::ROW_BYTES);
+  };
+  auto stageWH = [&](int buf, int kt) {
+    const uint32_t kb = (uint32_t)min(kt, nk - 1) * (C::BK * 2);
+    char *base = smem + buf * C::BUF_BYTES + C::OFF_WH + wave * 8 * C::ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < NHI; ++i) ca_glds16(Wb + offWH[i] + kb, base + i * 64 * C::ROW_BYTES);
+  };
+
+  f32x4 acc[8][NT_];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lane_off = (lane & 15) * C::ROW_BYTES + ((((lane >> 4) ^ ((lane & 15) >> 1)) & 7) << 4);
+  const int a_off = wm * 64 * C::ROW_BYTES + lane_off;  // + half offset + mi*16 rows
+
+  bf16x8 af[4][2], wl[NL][2], wh[NHI][2];
+  auto readA = [&](int buf, int h) {
+    const char *b = smem + buf * C::BUF_BYTES + (h ? C::OFF_AH : C::OFF_AL);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        af[mi][ks] = *(const bf16x8 *)(b + ((a_off + mi * 16 * C::ROW_BYTES) ^ (ks * 64)));
+  };
+  auto readWL = [&](int buf) {
+    const char *b = smem + buf * C::BUF_BYTES + C::OFF_WL;
+    const int w_off = wn * 16 * NL * C::ROW_BYTES + lane_off;
+#pragma unroll
+    for (int nj = 0; nj < NL; ++nj)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        wl[nj][ks] = *(const bf16x8 *)(b + ((w_off + nj * 16 * C::ROW_BYTES) ^ (ks * 64)));
+  };
+  auto readWH = [&](int buf) {
+    const char *b = smem + buf * C::BUF_BYTES + C::OFF_WH;
+    const int w_off = wn * 16 * NHI * C::ROW_BYTES + lane_off;
+#pragma unroll
+    for (int nj = 0; nj < NHI; ++nj)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        wh[nj][ks] = *(const bf16x8 *)(b + ((w_off + nj * 16 * C::ROW_BYTES) ^ (ks * 64)));
+  };
+#define CA_PP_MMA(MI0, NJ0, WF, NW)                                                                         \
+  {                                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)       \
+        _Pragma("unroll") for (int nj = 0; nj < (NW); ++nj) acc[(MI0) + mi][(NJ0) + nj] =                   \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nj][ks], af[mi][ks], acc[(MI0) + mi][(NJ0) + nj], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                          \
+  }
+#define CA_PP_SYNC()                        \
+  __builtin_amdgcn_sched_barrier(0);        \
+  __builtin_amdgcn_s_barrier();             \
+  __builtin_amdgcn_sched_barrier(0)
+#define CA_PP_WAIT_READS()                               \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+  __builtin_amdgcn_sched_barrier(0)
+
+  // ---- prologue: AL(0) WL(0) WH(0) AH(0) WL(1).  Group 1 executes no retire-wait between this
+  // barrier and group 0's first read of W-hi(0), so everything but AH(0), WL(1) must have landed.
+  stageA(0, 0, 0);
+  stageWL(0, 0);
+  stageWH(0, 0);
+  stageA(0, 1, 0);
+  stageWL(1, 1);
+  ca_wait_vmcnt<C::CNT_A + NL>();
+  CA_PP_SYNC();
+  if (wm == 1) { CA_PP_SYNC(); }  // stagger: group 1 runs one barrier behind group 0
+
+  // retire-waits leave the two youngest half tiles in flight: phase 1: WL(t+2 of the previous
+  // tile's phase 4) + AL; phase 2: AL + WH; phase 3: WH + AH; phase 4: AH + WL
+  for (int t = 0; t < nk; ++t) {
+    const int b = t & 1;
+    // phase 1: (A-lo, W-lo)
+    readA(b, 0);
+    readWL(b);
+    stageA(b ^ 1, 0, t + 1);
+    CA_PP_WAIT_READS();
+    CA_PP_SYNC();
+    CA_PP_MMA(0, 0, wl, NL);
+    ca_wait_vmcnt<NL + C::CNT_A>();
+    CA_PP_SYNC();
+    // phase 2: (A-lo, W-hi)
+    readWH(b);
+    stageWH(b ^ 1, t + 1);
+    CA_PP_WAIT_READS();
+    CA_PP_SYNC();
+    CA_PP_MMA(0, NL, wh, NHI);
+    ca_wait_vmcnt<C::CNT_A + NHI>();
+    CA_PP_SYNC();
+    // phase 3: (A-hi, W-hi)
+    readA(b, 1);
+    stageA(b ^ 1, 1, t + 1);
+    CA_PP_WAIT_READS();
+    CA_PP_SYNC();
+    CA_PP_MMA(4, NL, wh, NHI);
+    ca_wait_vmcnt<NHI + C::CNT_A>();
+    CA_PP_SYNC();
+    // phase 4: (A-hi, W-lo); W-lo of tile t+2 goes into the buffer whose W-lo was consumed in phase 1
+    stageWL(b, t + 2);
+    CA_PP_SYNC();
+    CA_PP_MMA(4, 0, wl, NL);
+    ca_wait_vmcnt<C::CNT_A + NL>();
+    CA_PP_SYNC();
+  }
+  if (wm == 0) { CA_PP_SYNC(); }
+  ca_wait_vmcnt<0>();  // no LDS-DMA may be outstanding when the workgroup retires
+
+  // ---- epilogue.  acc[mi][nj][r] = C[m][n]:
+  //   m = m0 + (mi>>2)*128 + wm*64 + 16*(mi&3) + (lane&15)
+  //   lo half (nj <  NL): n = n0 +          wn*16*NL  + 4*NL *(lane>>4) + 4*nj      + r
+  //   hi half (nj >= NL): n = n0 + 64*NL +  wn*16*NHI + 4*NHI*(lane>>4) + 4*(nj-NL) + r
+  const int g = lane >> 4;
+  int epi = P.epilogue;
+  char *outb = (char *)P.out;
+  int ldo = P.ldc;
+  int col_shift = 0;
+  if (epi == CA_EPI_SPLIT_GELU) {
+    if (n0 >= P.n_split) {
+      epi = CA_EPI_GELU_TANH;
+      outb = (char *)P.out2;
+      ldo = P.ld2;
+      col_shift = -P.n_split;
+    } else {
+      epi = CA_EPI_BIAS;
+    }
+  }
+  auto half_epilogue = [&](auto nfrag_tag, int nj0, int nb) {
+    constexpr int NF = decltype(nfrag_tag)::value;
+    float bias[4 * NF], gate_a[4 * NF], gate_b[4 * NF];
+#pragma unroll
+    for (int t = 0; t < 4 * NF; ++t) bias[t] = gate_a[t] = gate_b[t] = 0.f;
+    if (P.bias) {
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const bf16x4 b4 = *(const bf16x4 *)((const bf16 *)P.bias + nb + 4 * j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[4 * j + r] = (float)b4[r];
+      }
+    }
+    if (epi == CA_EPI_GATE_RESIDUAL) {
+      const float *g1 = P.gate + nb;
+      const float *g2 = (P.gate2 ? P.gate2 : P.gate) + nb;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const f32x4 ga = *(const f32x4 *)(g1 + 4 * j), gb = *(const f32x4 *)(g2 + 4 * j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gate_a[4 * j + r] = ga[r];
+          gate_b[4 * j + r] = gb[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int m = m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
+      if (m >= M) continue;
+      uint2 *op = (uint2 *)(outb + ((size_t)m * ldo + nb + col_shift) * 2);
+      uint2 res[NF];
+      const bool first = m < P.gate_rows;
+      if (epi == CA_EPI_GATE_RESIDUAL) {
+        const uint2 *rp = (const uint2 *)((const char *)P.resid + ((size_t)m * P.ldr + nb) * 2);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) res[j] = rp[j];
+      }
+      uint2 o[NF];
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[mi][nj0 + j][r] + bias[4 * j + r];
+          if (epi == CA_EPI_GELU_TANH) v[r] = ca_gelu_tanh(v[r]);
+        }
+        if (epi == CA_EPI_GATE_RESIDUAL) {
+          const bf16x4 r4 = __builtin_bit_cast(bf16x4, res[j]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (float)r4[r] + (first ? gate_a[4 * j + r] : gate_b[4 * j + r]) * v[r];
+        }
+        o[j] = make_uint2(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]));
+      }
+      if constexpr (NF == 2) {
+        *(uint4 *)op = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+      } else {
+        op[0] = o[0];
+      }
+    }
+  };
+  half_epilogue(std::integral_constant<int, NL>{}, 0, n0 + wn * 16 * NL + 4 * NL * g);
+  half_epilogue(std::integral_constant<int, NHI>{}, NL, n0 + 64 * NL + wn * 16 * NHI + 4 * NHI * g);
+}
+
+template <int NL, int NHI>
+int launch_pp(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
+  using C = PPCfg<NL, NHI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_pp_kernel<NL, NHI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) {
+      ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+      return CA_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((ca_gemm_pp_kernel<NL, NHI>), dim3(total_tiles), dim3(512), C::LDS_BYTES, stream, L);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ca_set_error("ca_gemm_bf16: launch failed: %s", hipGetErrorString(e));
+    return CA_ERR_LAUNCH;
+  }
+  return CA_OK;
+}
+
 template <int M_REP, int N_REP>
 int launch(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
   using C = Cfg<M_REP, N_REP>;
@@ -263,6 +588,9 @@ int launch(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
 
 int tile_n_of(int tile) {
   switch (tile) {
+    case CA_TILE_PP_256x256: return 256;
+    case CA_TILE_PP_256x192: return 192;
+    case CA_TILE_PP_256x128: return 128;
     case CA_TILE_256x256: return 256;
     case CA_TILE_256x192: return 192;
     case CA_TILE_256x128: return 128;
@@ -271,28 +599,37 @@ int tile_n_of(int tile) {
   }
 }
 
-// Pick the tile width that wastes the fewest CU-rounds (256 CUs, one workgroup per CU).
+// Pick the tile that minimises (rounds over the 256 CUs) x (time of one round).  Round times are
+// per 48 K-steps, measured on MI355X (tools/bench_kernels.py): they only need to rank the choices.
 int auto_tile(const ca_gemm_problem *p, int n) {
-  static const int cands[] = {CA_TILE_256x256, CA_TILE_256x192, CA_TILE_256x128, CA_TILE_256x64};
+  static const struct { int tile; double round_us; } cands[] = {
+      {CA_TILE_PP_256x256, 80.0}, {CA_TILE_PP_256x192, 70.5}, {CA_TILE_PP_256x128, 51.0}, {CA_TILE_256x64, 35.0}};
   int best = 0;
   double best_cost = 1e300;
-  for (int c : cands) {
-    const int bn = tile_n_of(c);
+  for (const auto &c : cands) {
+    const int bn = tile_n_of(c.tile);
     bool ok = true;
+    double work = 0;  // tile-rounds weighted by K (a workgroup's time is proportional to its K loop)
     long tiles = 0;
+    int kmax = 0;
     for (int i = 0; i < n; ++i) {
       if (p[i].N % bn) ok = false;
       if (p[i].epilogue == CA_EPI_SPLIT_GELU && p[i].n_split % bn) ok = false;
-      tiles += (long)((p[i].M + 255) / 256) * (p[i].N / bn);
+      const long t = (long)((p[i].M + 255) / 256) * (p[i].N / bn);
+      tiles += t;
+      work += (double)t * p[i].K;
+      if (p[i].K > kmax) kmax = p[i].K;
     }
     if (!ok) continue;
-    const long rounds = (tiles + 255) / 256;
-    // per-tile time ~ BN plus a fixed per-tile overhead that penalises narrow tiles
-    const double cost = (double)rounds * (bn + 48.0);
+    // makespan estimate: at least one longest tile, at least the K-weighted work spread over 256 CUs
+    double rounds = work / kmax / 256.0;
+    rounds = rounds <= 1.0 ? 1.0 : (double)(long)(rounds + 0.999);
+    const double cost = rounds * c.round_us * kmax;
     if (cost < best_cost) {
       best_cost = cost;
-      best = c;
+      best = c.tile;
     }
+    (void)tiles;
   }
   return best;
 }
@@ -385,6 +722,9 @@ extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems,
   }
   hipStream_t s = (hipStream_t)stream;
   switch (tile) {
+    case CA_TILE_PP_256x256: return launch_pp<2, 2>(L, total, s);
+    case CA_TILE_PP_256x192: return launch_pp<2, 1>(L, total, s);
+    case CA_TILE_PP_256x128: return launch_pp<1, 1>(L, total, s);
     case CA_TILE_256x256: return launch<8, 4>(L, total, s);
     case CA_TILE_256x192: return launch<8, 3>(L, total, s);
     case CA_TILE_256x128: return launch<8, 2>(L, total, s);

@@ -62,7 +62,9 @@ enum {
                             /* (single block linear1 -> qkv | mlp, single_stream_block:49) */
 };
 
-enum { CA_TILE_AUTO = 0, CA_TILE_256x256 = 1, CA_TILE_256x192 = 2, CA_TILE_256x128 = 3, CA_TILE_256x64 = 4 };
+/* tile = block tile M x N; the PP ("ping-pong") kernels are the pipelined fast path */
+enum { CA_TILE_AUTO = 0, CA_TILE_256x256 = 1, CA_TILE_256x192 = 2, CA_TILE_256x128 = 3, CA_TILE_256x64 = 4,
+       CA_TILE_PP_256x256 = 5, CA_TILE_PP_256x128 = 6, CA_TILE_PP_256x192 = 7 };
 
 #define CA_GEMM_MAX_PROBLEMS 2
 

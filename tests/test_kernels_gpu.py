@@ -39,52 +39,59 @@ def test_gemm_identity_asymmetric():
     a = torch.eye(256, K, device=DEV).bfloat16()
     w = (torch.arange(N, device=DEV)[:, None] * 3 + torch.arange(K, device=DEV)[None, :] * 5) % 251
     w = (w.float() - 125).bfloat16()  # integers < 256: exact in bf16
-    for tile in (L.TILE_256x256, L.TILE_256x192 if N % 192 == 0 else L.TILE_256x128, L.TILE_256x128, L.TILE_256x64):
+    w = torch.cat((w, w[:128] + 1))  # N = 384: divisible by every tile width
+    N = 384
+    for tile in (L.TILE_256x128, L.TILE_256x64, L.TILE_PP_256x192, L.TILE_PP_256x128, L.TILE_256x192):
         out = ops.linear(a, w, None, tile=tile)
         assert torch.equal(out.float(), w.float().t().contiguous()), f"tile {tile}"
 
 
 @pytest.mark.parametrize("tile,N", [(L.TILE_256x256, 512), (L.TILE_256x192, 384), (L.TILE_256x128, 384),
-                                    (L.TILE_256x64, 64), (L.TILE_AUTO, 768)])
-@pytest.mark.parametrize("M", [4, 260, 513])
-def test_gemm_bias_tails(tile, N, M):
-    K = 192
+                                    (L.TILE_256x64, 64), (L.TILE_AUTO, 768), (L.TILE_PP_256x256, 512),
+                                    (L.TILE_PP_256x128, 384), (L.TILE_PP_256x192, 576)])
+@pytest.mark.parametrize("M,K", [(4, 192), (260, 64), (513, 192), (300, 1024)])
+def test_gemm_bias_tails(tile, N, M, K):
     a, w, b = rnd(M, K), rnd(N, K, scale=0.1), rnd(N)
     out = ops.linear(a, w, b, tile=tile)
     ref = a.float() @ w.float().t() + b.float()
     close(out, ref, atol=2e-2)
 
 
-def test_gemm_epilogues_and_strides():
-    M, N, K = 300, 512, 320
+@pytest.mark.parametrize("tile,N", [(L.TILE_256x256, 512), (L.TILE_PP_256x256, 512), (L.TILE_PP_256x128, 512),
+                                    (L.TILE_PP_256x192, 768)])
+def test_gemm_epilogues_and_strides(tile, N):
+    M, K = 300, 320
     big = rnd(M, K + 64)
     a = big[:, 32:32 + K]  # row stride K+64, 16-byte aligned offset
     w, b = rnd(N, K, scale=0.1), rnd(N)
     lin = a.float() @ w.float().t() + b.float()
-    out = ops.linear(a, w, b, epilogue=L.EPI_GELU_TANH)
+    out = ops.linear(a, w, b, epilogue=L.EPI_GELU_TANH, tile=tile)
     close(out, torch.nn.functional.gelu(lin, approximate="tanh"), atol=2e-2)
     # gate * x + residual with two gate vectors (rows < 7 use gate, the rest gate2), in place
     resid = rnd(M, N)
     g1, g2 = rnd(N).float(), rnd(N, seed=5).float()
     ref = resid.float() + torch.where(torch.arange(M, device=DEV)[:, None] < 7, g1[None], g2[None]) * lin
     x = resid.clone()
-    ops.gemm([ops.Gemm(a, w, b, x, L.EPI_GATE_RESIDUAL, resid=x, gate=g1, gate2=g2, gate_rows=7)])
+    ops.gemm([ops.Gemm(a, w, b, x, L.EPI_GATE_RESIDUAL, resid=x, gate=g1, gate2=g2, gate_rows=7)], tile)
     close(x, ref, atol=3e-2)
-    # split: first 256 columns plain, remaining 256 GELU into a strided destination
-    o1 = torch.zeros(M, 256, device=DEV, dtype=torch.bfloat16)
-    cat = torch.zeros(M, 128 + 256, device=DEV, dtype=torch.bfloat16)
-    ops.gemm([ops.Gemm(a, w, b, o1, L.EPI_SPLIT_GELU, out2=cat[:, 128:], n_split=256)])
-    close(o1, lin[:, :256], atol=2e-2)
-    close(cat[:, 128:], torch.nn.functional.gelu(lin[:, 256:], approximate="tanh"), atol=2e-2)
+    # split: first ns columns plain, the rest GELU into a strided destination
+    ns = 384 if N == 768 else 256
+    o1 = torch.zeros(M, ns, device=DEV, dtype=torch.bfloat16)
+    cat = torch.zeros(M, 128 + N - ns, device=DEV, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(a, w, b, o1, L.EPI_SPLIT_GELU, out2=cat[:, 128:], n_split=ns)], tile)
+    close(o1, lin[:, :ns], atol=2e-2)
+    close(cat[:, 128:], torch.nn.functional.gelu(lin[:, ns:], approximate="tanh"), atol=2e-2)
     assert cat[:, :128].abs().max() == 0
 
 
-def test_gemm_grouped_two_problems():
+@pytest.mark.parametrize("tile", [L.TILE_AUTO, L.TILE_256x256, L.TILE_PP_256x256, L.TILE_PP_256x128, L.TILE_PP_256x192])
+def test_gemm_grouped_two_problems(tile):
     a0, w0, b0 = rnd(700, 256), rnd(768, 256, scale=0.1), rnd(768)
-    a1, w1, b1 = rnd(260, 128), rnd(512, 128, scale=0.1), rnd(512)
+    n1 = 384 if tile == L.TILE_PP_256x192 else 512
+    a1, w1, b1 = rnd(260, 128), rnd(n1, 128, scale=0.1), rnd(n1)
     o0 = torch.empty(700, 768, device=DEV, dtype=torch.bfloat16)
-    o1 = torch.empty(260, 512, device=DEV, dtype=torch.bfloat16)
-    ops.gemm([ops.Gemm(a0, w0, b0, o0), ops.Gemm(a1, w1, b1, o1, L.EPI_GELU_TANH)])
+    o1 = torch.empty(260, n1, device=DEV, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(a0, w0, b0, o0), ops.Gemm(a1, w1, b1, o1, L.EPI_GELU_TANH)], tile)
     close(o0, a0.float() @ w0.float().t() + b0.float(), atol=2e-2)
     close(o1, torch.nn.functional.gelu(a1.float() @ w1.float().t() + b1.float(), approximate="tanh"), atol=2e-2)
 
@@ -97,13 +104,28 @@ def test_gemm_rejects_bad_arguments():
         ops.linear(rnd(16, 128), rnd(100, 128), None)  # N not a multiple of any tile width
 
 
-def test_gemm_full_size_flux_shapes():
+def test_gemm_pipelined_kernel_repeatable_under_load():
+    """The ping-pong kernel hands tiles between waves through LDS-DMA + counted waits; a protocol
+    slip shows up as rare wrong tiles, so compare many back-to-back launches bit for bit and
+    against fp32 (different shapes keep every CU busy with uneven neighbours)."""
+    M, N, K = 4096, 3072, 3072
+    a, w = rnd(M, K), rnd(N, K, scale=0.02)
+    ref = a.float() @ w.float().t()
+    first = ops.linear(a, w, None, tile=L.TILE_PP_256x256)
+    close(first, ref, atol=3e-2)
+    for i in range(20):
+        out = ops.linear(a, w, None, tile=(L.TILE_PP_256x256, L.TILE_PP_256x128, L.TILE_PP_256x192)[i % 3])
+        assert torch.equal(out, first), f"launch {i} differs"
+
+
+@pytest.mark.parametrize("tile", [L.TILE_256x256, L.TILE_PP_256x256])
+def test_gemm_full_size_flux_shapes(tile):
     """M=4352 (T+L), the single-block linear1 split: N=21504 -> qkv 9216 | mlp 12288, K=3072."""
     M, K = 4352, 3072
     a, w, b = rnd(M, K), rnd(21504, K, scale=0.02), rnd(21504)
     qkv = torch.empty(M, 9216, device=DEV, dtype=torch.bfloat16)
     cat = torch.empty(M, 15360, device=DEV, dtype=torch.bfloat16)
-    ops.gemm([ops.Gemm(a, w, b, qkv, L.EPI_SPLIT_GELU, out2=cat[:, 3072:], n_split=9216)])
+    ops.gemm([ops.Gemm(a, w, b, qkv, L.EPI_SPLIT_GELU, out2=cat[:, 3072:], n_split=9216)], tile)
     ref = a.float() @ w.float().t() + b.float()
     close(qkv, ref[:, :9216], atol=3e-2)
     close(cat[:, 3072:], torch.nn.functional.gelu(ref[:, 9216:], approximate="tanh"), atol=3e-2)

@@ -56,17 +56,22 @@ def bench_attn(n, nh=24, C=0):
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
-    for tile in (L.TILE_256x256, L.TILE_256x192, L.TILE_256x128):
+    PP, PP1, PP2 = L.TILE_PP_256x256, L.TILE_PP_256x128, L.TILE_PP_256x192
+    for tile in (PP, PP2, PP1):
         bench_gemm(4096, 9216, 3072, tile, name="qkv")
-    for tile in (L.TILE_256x256, L.TILE_256x192, L.TILE_256x128):
+    for tile in (PP, PP2, PP1):
         bench_gemm(4096, 3072, 3072, tile, L.EPI_GATE_RESIDUAL, name="proj")
-    bench_gemm(4096, 12288, 3072, L.TILE_256x256, L.EPI_GELU_TANH, name="mlp0")
-    for tile in (L.TILE_256x256, L.TILE_256x192):
+    for tile in (PP, PP2):
+        bench_gemm(4096, 12288, 3072, tile, L.EPI_GELU_TANH, name="mlp0")
+    for tile in (PP, PP2, PP1):
         bench_gemm(4096, 3072, 12288, tile, L.EPI_GATE_RESIDUAL, name="mlp2")
-    bench_gemm(4352, 21504, 3072, L.TILE_256x256, name="linear1")
-    bench_gemm(4352, 3072, 15360, L.TILE_256x256, L.EPI_GATE_RESIDUAL, name="linear2")
-    bench_gemm(8192, 8192, 8192, L.TILE_256x256, name="8k")
-    bench_gemm(260, 9216, 3072, L.TILE_256x256, name="txt-qkv")
+    for tile in (PP, PP2):
+        bench_gemm(4352, 21504, 3072, tile, name="linear1")
+    for tile in (PP, PP2, PP1):
+        bench_gemm(4352, 3072, 15360, tile, L.EPI_GATE_RESIDUAL, name="linear2")
+    for tile in (PP,):
+        bench_gemm(8192, 8192, 8192, tile, name="8k")
+    bench_gemm(260, 9216, 3072, PP, name="txt-qkv")
     bench_attn(4352)
     bench_attn(4352, C=4)
     bench_attn(4608)
