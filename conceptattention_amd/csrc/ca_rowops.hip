@@ -352,9 +352,9 @@ extern "C" int ca_qknorm_rope_bf16(void *qkv, int32_t ld, int32_t M, int32_t num
 extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void *W, const void *bias, float *out,
                             int32_t ldo, int32_t N, int32_t K, int32_t silu_input, int32_t accumulate,
                             ca_stream_t stream) {
-  if (!x || !W || !out || nv < 1 || nv > 4 || N < 1 || K < 8 || K % 8 || K > 4096 || ldx < K || ldo < N ||
+  if (!x || !W || !out || nv < 1 || nv > 8 || N < 1 || K < 8 || K % 8 || K > 4096 || ldx < K || ldo < N ||
       (((uintptr_t)W) & 15)) {
-    ca_set_error("ca_gemv_bf16: bad arguments (nv=%d N=%d K=%d; need 1<=nv<=4, K%%8==0, K<=4096)", nv, N, K);
+    ca_set_error("ca_gemv_bf16: bad arguments (nv=%d N=%d K=%d; need 1<=nv<=8, K%%8==0, K<=4096)", nv, N, K);
     return CA_ERR_ARG;
   }
   const int grid = (N + 3) / 4 < 4096 ? (N + 3) / 4 : 4096;
@@ -363,11 +363,30 @@ extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void 
 #define CA_GEMV_LAUNCH(NV)                                                                                     \
   hipLaunchKernelGGL(ca_gemv_kernel<NV>, dim3(grid), dim3(256), lds, s, x, ldx, (const bf16 *)W, (const bf16 *)bias, \
                      out, ldo, N, K, silu_input, accumulate)
+  if (lds > 64 * 1024) {  // 5..8 vectors of K > 2048: opt in to the large dynamic-LDS carve-out once
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipSuccess;
+      const void *fns[] = {(const void *)ca_gemv_kernel<5>, (const void *)ca_gemv_kernel<6>,
+                           (const void *)ca_gemv_kernel<7>, (const void *)ca_gemv_kernel<8>};
+      for (const void *f : fns)
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4);
+      if (e != hipSuccess) {
+        ca_set_error("ca_gemv_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return CA_ERR_LAUNCH;
+      }
+      attr_done = true;
+    }
+  }
   switch (nv) {
     case 1: CA_GEMV_LAUNCH(1); break;
     case 2: CA_GEMV_LAUNCH(2); break;
     case 3: CA_GEMV_LAUNCH(3); break;
-    default: CA_GEMV_LAUNCH(4); break;
+    case 4: CA_GEMV_LAUNCH(4); break;
+    case 5: CA_GEMV_LAUNCH(5); break;
+    case 6: CA_GEMV_LAUNCH(6); break;
+    case 7: CA_GEMV_LAUNCH(7); break;
+    default: CA_GEMV_LAUNCH(8); break;
   }
 #undef CA_GEMV_LAUNCH
   return check_launch("ca_gemv_bf16");

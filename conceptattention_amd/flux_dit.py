@@ -137,6 +137,8 @@ class HipFluxDiT:
         self.weights = weights if weights is not None else FluxWeights(params, self.device)
         self._ws_key = None
         self._rope_key = None
+        self._mod_cur = None
+        self._mod_steps = None
 
     # ---- nn.Module-like surface the reference's loader touches (image_generator.py:37-44,183,194)
     def load_state_dict(self, sd, strict: bool = True, assign: bool = False):
@@ -206,19 +208,21 @@ class HipFluxDiT:
         """fp32 view of one modulation chunk: name = '<block>.lin' base, row 0 = vec, 1 = concept_vec."""
         H = self.hidden_size
         o = self.weights.mod_offset[name] + chunk * H
-        return self.MOD[row, o:o + H]
+        return self._mod_cur[row, o:o + H]
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def __call__(self, img, img_ids, txt, txt_ids, concepts, concept_ids, concept_vec, timesteps, y,
                  guidance=None, stop_after_multimodal_attentions: bool = False, edit_metadata=None,
                  iteration=None, joint_attention_kwargs=None, return_vectors: bool = True,
-                 heatmaps: Optional[HeatmapRequest] = None, **kwargs):
+                 heatmaps: Optional[HeatmapRequest] = None, cond_slot: Optional[int] = None, **kwargs):
         """Same keyword contract as ModifiedFluxDiT.forward (modified_flux_dit.py:75-92).
 
         Extra (HIP-path) keywords: ``return_vectors=False`` skips materialising the four
         per-layer vector stacks (the dict is then empty); ``heatmaps`` accumulates
-        softmax-over-concepts maps for the requested layers inside the forward."""
+        softmax-over-concepts maps for the requested layers inside the forward; ``cond_slot=i``
+        uses step i of a preceding ``precompute_conditioning`` call instead of recomputing the
+        conditioning vectors from ``timesteps`` / ``y`` / ``guidance``."""
         assert concept_vec is not None, "Concept vectors must be provided for this implementation."
         if img.ndim != 3 or txt.ndim != 3:
             raise ValueError("Input img and txt tensors must have 3 dimensions.")
@@ -244,22 +248,11 @@ class HipFluxDiT:
                   ops.Gemm(self.TXT_IN, W["txt_in.weight"], W["txt_in.bias"], X[:CT])])
 
         # ---- conditioning vectors: row 0 = vec (y), row 1 = concept_vec (modified_flux_dit.py:99-119)
-        self.TVAL.copy_(timesteps.reshape(-1)[:1].float().expand(2))
-        ops.timestep_embedding(self.TVAL, self.TEMB)
-        ops.gemv(self.TEMB, W["time_in.in_layer.weight"], W["time_in.in_layer.bias"], self.HVEC)
-        ops.gemv(self.HVEC, W["time_in.out_layer.weight"], W["time_in.out_layer.bias"], self.VEC, silu_input=True)
-        if p.guidance_embed:
-            self.TVAL.copy_(guidance.reshape(-1)[:1].float().expand(2))
-            ops.timestep_embedding(self.TVAL, self.TEMB)
-            ops.gemv(self.TEMB, W["guidance_in.in_layer.weight"], W["guidance_in.in_layer.bias"], self.HVEC)
-            ops.gemv(self.HVEC, W["guidance_in.out_layer.weight"], W["guidance_in.out_layer.bias"], self.VEC,
-                     silu_input=True, accumulate=True)
-        self.YIN[0].copy_(y.reshape(-1))
-        self.YIN[1].copy_(concept_vec.reshape(-1))
-        ops.gemv(self.YIN, W["vector_in.in_layer.weight"], W["vector_in.in_layer.bias"], self.HVEC)
-        ops.gemv(self.HVEC, W["vector_in.out_layer.weight"], W["vector_in.out_layer.bias"], self.VEC,
-                 silu_input=True, accumulate=True)
-        self._modulations()
+        if cond_slot is not None:
+            self._mod_cur = self._mod_steps[cond_slot]
+        else:
+            self._mod_cur = self.MOD
+            self._conditioning(timesteps, y, concept_vec, guidance)
 
         out = {k: [] for k in DICT_KEYS} if return_vectors else {}
         for i in range(p.depth):
@@ -277,10 +270,71 @@ class HipFluxDiT:
         ops.gemm([ops.Gemm(XM[CT:], W["final_layer.linear.weight"], W["final_layer.linear.bias"], self.PRED)])
         return self.PRED.unsqueeze(0).clone(), out
 
+    def _conditioning(self, timesteps, y, concept_vec, guidance):
+        """vec / concept_vec and all modulations for ONE step into self.VEC / self.MOD."""
+        p, W = self.params, self.weights
+        self.TVAL.copy_(timesteps.reshape(-1)[:1].float().expand(2))
+        ops.timestep_embedding(self.TVAL, self.TEMB)
+        ops.gemv(self.TEMB, W["time_in.in_layer.weight"], W["time_in.in_layer.bias"], self.HVEC)
+        ops.gemv(self.HVEC, W["time_in.out_layer.weight"], W["time_in.out_layer.bias"], self.VEC, silu_input=True)
+        if p.guidance_embed:
+            self.TVAL.copy_(guidance.reshape(-1)[:1].float().expand(2))
+            ops.timestep_embedding(self.TVAL, self.TEMB)
+            ops.gemv(self.TEMB, W["guidance_in.in_layer.weight"], W["guidance_in.in_layer.bias"], self.HVEC)
+            ops.gemv(self.HVEC, W["guidance_in.out_layer.weight"], W["guidance_in.out_layer.bias"], self.VEC,
+                     silu_input=True, accumulate=True)
+        self.YIN[0].copy_(y.reshape(-1))
+        self.YIN[1].copy_(concept_vec.reshape(-1))
+        ops.gemv(self.YIN, W["vector_in.in_layer.weight"], W["vector_in.in_layer.bias"], self.HVEC)
+        ops.gemv(self.HVEC, W["vector_in.out_layer.weight"], W["vector_in.out_layer.bias"], self.VEC,
+                 silu_input=True, accumulate=True)
+        self._modulations()
+
+    def precompute_conditioning(self, timesteps, y, concept_vec, guidance=None):
+        """Conditioning vectors and every block's adaLN modulation for ALL diffusion steps up front
+        (they depend only on (t, guidance, y), never on the activations): the 6.4 GB of modulation
+        weights are streamed once per 4 steps instead of once per step.  Step i is then selected
+        with ``cond_slot=i`` in the model call.  Same arithmetic as the in-call path
+        (modified_flux_dit.py:99-119, flux/modules/layers.py:113-126)."""
+        p, W, dev = self.params, self.weights, self.device
+        if p.guidance_embed and guidance is None:
+            raise ValueError("Didn't get guidance strength for guidance distilled model.")
+        n = len(timesteps)
+        H = p.hidden_size
+        f32 = dict(device=dev, dtype=torch.float32)
+        tv = torch.tensor([float(t) for t in timesteps for _ in range(2)], **f32)
+        temb = torch.empty(2 * n, 256, **f32)
+        hv = torch.empty(2 * n, H, **f32)
+        vecs = torch.empty(2 * n, H, **f32)
+        yin = torch.empty(2 * n, p.vec_in_dim, **f32)
+        yin[0::2] = y.reshape(1, -1).float()
+        yin[1::2] = concept_vec.reshape(1, -1).float()
+        mod = torch.empty(n, 2, W.mod_rows, **f32)
+        mod2 = mod.view(2 * n, W.mod_rows)
+        ops.timestep_embedding(tv, temb)
+        if p.guidance_embed:
+            gemb = torch.empty(2 * n, 256, **f32)
+            ops.timestep_embedding(torch.full((2 * n,), float(guidance), **f32), gemb)
+        for r0 in range(0, 2 * n, 8):
+            r = slice(r0, min(r0 + 8, 2 * n))
+            ops.gemv(temb[r], W["time_in.in_layer.weight"], W["time_in.in_layer.bias"], hv[r])
+            ops.gemv(hv[r], W["time_in.out_layer.weight"], W["time_in.out_layer.bias"], vecs[r], silu_input=True)
+            if p.guidance_embed:
+                ops.gemv(gemb[r], W["guidance_in.in_layer.weight"], W["guidance_in.in_layer.bias"], hv[r])
+                ops.gemv(hv[r], W["guidance_in.out_layer.weight"], W["guidance_in.out_layer.bias"], vecs[r],
+                         silu_input=True, accumulate=True)
+            ops.gemv(yin[r], W["vector_in.in_layer.weight"], W["vector_in.in_layer.bias"], hv[r])
+            ops.gemv(hv[r], W["vector_in.out_layer.weight"], W["vector_in.out_layer.bias"], vecs[r],
+                     silu_input=True, accumulate=True)
+            ops.gemv(vecs[r], W.mod_w, W.mod_b, mod2[r], silu_input=True)
+        self._mod_steps = mod
+        return n
+
     def _modulations(self):
         """Every block's adaLN shift/scale/gate from VEC (row 0 = vec, row 1 = concept_vec) in one
         weight-streaming launch (Modulation, flux/modules/layers.py:113-126)."""
         ops.gemv(self.VEC, self.weights.mod_w, self.weights.mod_b, self.MOD, silu_input=True)
+        self._mod_cur = self.MOD
 
     def _double_block(self, i, C, T, Li, joint_attention_kwargs=None, out=None, return_vectors=False,
                       heatmaps=None):

@@ -175,7 +175,7 @@ def qknorm_rope(qkv, num_heads, segments, rope_cos_sin, q_prerope=None) -> None:
 
 
 def gemv(x, w, bias, out, silu_input=False, accumulate=False) -> None:
-    """out[v,:] (+)= f(x[v,:]) @ w.T + bias; x fp32 [nv,K] (nv<=4), w bf16 [N,K], out fp32 [nv,N]."""
+    """out[v,:] (+)= f(x[v,:]) @ w.T + bias; x fp32 [nv,K] (nv<=8), w bf16 [N,K], out fp32 [nv,N]."""
     lib = L.load()
     _chk(x, torch.float32, "x"), _chk(w, torch.bfloat16, "w"), _chk(out, torch.float32, "out")
     if not w.is_contiguous():

@@ -102,13 +102,17 @@ def denoise(model, img, img_ids, txt, txt_ids, vec, timesteps: list[float], guid
     out = {k: [] for k in DICT_KEYS} if return_vectors else {}
     guidance_vec = torch.full((img.shape[0],), guidance, device=img.device, dtype=torch.float32)
     sel = None if heatmap_timesteps is None else set(heatmap_timesteps)
+    # HIP path: all steps' conditioning vectors / adaLN modulations in one pass over the weights
+    slots = hasattr(model, "precompute_conditioning")
+    if slots:
+        model.precompute_conditioning(timesteps[:-1], vec, concept_vec, guidance)
     for it, (t_curr, t_prev) in enumerate(zip(timesteps[:-1], timesteps[1:])):
         t_vec = torch.full((img.shape[0],), t_curr, dtype=torch.float32, device=img.device)
         hm = heatmaps if (heatmaps is not None and (sel is None or it in sel)) else None
         pred, d = model(img=img, img_ids=img_ids, txt=txt, txt_ids=txt_ids, concepts=concepts,
                         concept_ids=concept_ids, concept_vec=concept_vec, y=vec, timesteps=t_vec,
                         guidance=guidance_vec, iteration=it, joint_attention_kwargs=joint_attention_kwargs,
-                        return_vectors=return_vectors, heatmaps=hm)
+                        return_vectors=return_vectors, heatmaps=hm, **({"cond_slot": it} if slots else {}))
         ops.axpy(img, pred.contiguous(), t_prev - t_curr)  # img = img + (t_prev - t_curr) * pred  (:141)
         if return_intermediate_images:
             intermediates.append(img.clone())

@@ -151,7 +151,7 @@ int ca_qknorm_rope_bf16(void *qkv, int32_t ld, int32_t M, int32_t num_heads,
 
 /* ------------------------------------------------------------------------------------------
  * Small-batch matrix-vector products (weight streaming, HBM-bound):
- *   out[v,n] (+)= sum_k f(x[v,k]) * W[n,k] + bias[n],  v < nv <= 4,  f = SiLU or identity.
+ *   out[v,n] (+)= sum_k f(x[v,k]) * W[n,k] + bias[n],  v < nv <= 8,  f = SiLU or identity.
  * Modulation (flux/modules/layers.py:113-126), MLPEmbedder (:52-60), LastLayer.adaLN (:246,249).
  */
 int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void *W, const void *bias, float *out,

@@ -49,7 +49,7 @@ def test_argument_rejection_needs_no_gpu(lib):
     assert lib.ca_attn_fwd_bf16(a, 1, 24, 0.1, None) == -1
     assert lib.ca_attn_fwd_bf16(a, 3, 24, 0.1, None) == -1
     assert lib.ca_axpy_bf16(None, None, 1.0, 0, None) == -1
-    assert lib.ca_gemv_bf16(None, 5, 0, None, None, None, 0, 0, 0, 0, 0, None) == -1
+    assert lib.ca_gemv_bf16(None, 9, 0, None, None, None, 0, 0, 0, 0, 0, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -234,7 +234,8 @@ def test_qknorm_rope_matches_oracle():
     assert torch.equal(qkv.view(M, 3, nh, 128)[:, 2], orig.view(M, 3, nh, 128)[:, 2])  # v untouched
 
 
-@pytest.mark.parametrize("nv,K,N", [(1, 256, 3072), (2, 3072, 18432), (3, 768, 100), (4, 4096, 64)])
+@pytest.mark.parametrize("nv,K,N", [(1, 256, 3072), (2, 3072, 18432), (3, 768, 100), (4, 4096, 64), (8, 3072, 6144),
+                                    (6, 256, 512)])
 def test_gemv(nv, K, N):
     x = torch.randn(nv, K, device=DEV)
     w, b = rnd(N, K, scale=0.05), rnd(N)

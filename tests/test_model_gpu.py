@@ -96,6 +96,28 @@ def test_tiny_stop_after_multimodal_and_fused_heatmaps():
     assert maxabs(req.cross_space.view(1, C, 16, 16), hc) < 5e-3  # cross logits have std > 1: bf16 q rounding
 
 
+@pytest.mark.parametrize("guidance_embed", [False, True])
+def test_precomputed_conditioning_equals_per_step(guidance_embed):
+    """precompute_conditioning (all steps' modulations in one weight pass) is bit-identical to the
+    per-call path, also for more than 4 steps (two gemv passes)."""
+    p, sd, inp = tiny_case(guidance_embed, depth=1, singles=1)
+    m = HipFluxDiT(p, DEV)
+    m.load_state_dict(sd)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    img = O.patchify(inp["latent"]).to(DEV)
+    ts = [1.0, 0.8, 0.6, 0.4, 0.2]
+    kw = dict(img=img, img_ids=d["img_ids"], txt=d["txt"], txt_ids=d["txt_ids"], concepts=d["concepts"],
+              concept_ids=d["concept_ids"], concept_vec=d["concept_vec"], y=d["vec"],
+              guidance=torch.tensor([2.0], device=DEV))
+    ref = [m(timesteps=torch.tensor([t], device=DEV), **kw) for t in ts]
+    m.precompute_conditioning(ts, d["vec"], d["concept_vec"], 2.0)
+    for i, t in enumerate(ts):
+        pred, dd = m(timesteps=torch.tensor([123.0], device=DEV), cond_slot=i, **kw)  # timesteps ignored
+        assert torch.equal(pred, ref[i][0])
+        for k in DICT_KEYS:
+            assert torch.equal(dd[k], ref[i][1][k]), (i, k)
+
+
 def test_tiny_ablation_branches():
     p, sd, inp = tiny_case(depth=1, singles=0)
     for cross in (True, False):
