@@ -44,6 +44,18 @@ __device__ unsigned long long ca_attn_dbg[32];
 #define CA_ACC(SLOT, T0, T1)
 #endif
 
+// priority policy of the ping-pong kernel: 0 none, 1 raise around every matrix phase, 2 static for group 1
+#ifndef CA_ATTN_PRIO_MODE
+#define CA_ATTN_PRIO_MODE 1
+#endif
+#if CA_ATTN_PRIO_MODE == 1
+#define CA_PRIO_HI() __builtin_amdgcn_s_setprio(1)
+#define CA_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define CA_PRIO_HI()
+#define CA_PRIO_LO()
+#endif
+
 constexpr int KV_TILE = 64;
 constexpr int TILE_BYTES = KV_TILE * 256;  // one K or V tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;
@@ -186,24 +198,29 @@ __global__ __launch_bounds__(512, 2) void ca_attn_kernel(const AttnLaunch L) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx * sl2);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
+      // rescale O^T only when some row's running maximum grows (exact: alpha == 1 otherwise);
+      // after the first few tiles this is rare, which removes 64 multiplies per tile
+      if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
       float rs = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_new));
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_run));
           s[kb][r] = p;
           rs += p;
         }
-      l_run = l_run * alpha + rs;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      l_run += rs;
       // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; P^T fragments straight from the S^T registers
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void ca_attn_pp_kernel(const AttnLaunch L) 
       const int kk = min(tile * KV_TILE + r, nkeys - 1);
       const bool s0 = kk < n0;
       const bf16 *src = (s0 ? src0 : src1) + (size_t)(s0 ? kk : kk - n0) * ldkv + ((st_cp ^ swz) << 3);
-      ca_glds16(src, smem + (grp ? PP_RING * TILE_BYTES : 0) + (tile % PP_RING) * TILE_BYTES + q * 1024);
+      ca_glds16_asm(src, smem + (grp ? PP_RING * TILE_BYTES : 0) + (tile % PP_RING) * TILE_BYTES + q * 1024);
     }
   };
 #define CA_ATTN_DMA_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -440,9 +457,15 @@ __global__ __launch_bounds__(512, 2) void ca_attn_pp_kernel(const AttnLaunch L) 
 
   // ---- prologue: K(0) (group 0) and V(0) (group 1) land before the first barrier
   stage_tile(0);
-  CA_ATTN_DMA_DONE();
+  // vmcnt(0) through the BUILTIN (0x0F70 = vmcnt 0, expcnt/lgkmcnt untouched): besides retiring the DMA it
+  // tells hipcc's wait-count pass that the Q-fragment loads above have landed, so it inserts no
+  // vmcnt waits for them inside the tile loop (where they would drain the hand-counted DMA).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   CA_ATTN_SYNC();
   if (grp == 1) { CA_ATTN_SYNC(); }  // stagger: group 1 runs one barrier behind group 0
+#if CA_ATTN_PRIO_MODE == 2
+  if (grp == 1) __builtin_amdgcn_s_setprio(1);  // static: the younger half wins arbitration throughout
+#endif
 
   // Staging schedule, identical for both groups on their own matrix (3-deep rings): tile t+1 is
   // DMA-issued at the start of the group's X(t) and retired (vmcnt 0) at the end of its Y(t).
@@ -454,9 +477,9 @@ __global__ __launch_bounds__(512, 2) void ca_attn_pp_kernel(const AttnLaunch L) 
   if (active) {  // X(0): QK(0) only
 #pragma unroll
     for (int m = 16; m < 16 + W; ++m) fr[m % W] = frag(m, 0, 0);
-    __builtin_amdgcn_s_setprio(1);
+    CA_PRIO_HI();
     CA_ATTN_STREAM(16, 32, 0, 0)
-    __builtin_amdgcn_s_setprio(0);
+    CA_PRIO_LO();
   }
   CA_ATTN_SYNC();
 #ifdef CA_ATTN_STAMP
@@ -479,9 +502,9 @@ __global__ __launch_bounds__(512, 2) void ca_attn_pp_kernel(const AttnLaunch L) 
     // ---- X(t+1): matrix phase  PV(t) + QK(t+1)
     if (t + 2 < nt) stage_tile(t + 2);
     if (active) {
-      __builtin_amdgcn_s_setprio(1);
+      CA_PRIO_HI();
       CA_ATTN_STREAM(0, 32, t, t + 1)
-      __builtin_amdgcn_s_setprio(0);
+      CA_PRIO_LO();
     }
     CA_STAMP(ts4);
     CA_ATTN_SYNC();
@@ -508,9 +531,9 @@ __global__ __launch_bounds__(512, 2) void ca_attn_pp_kernel(const AttnLaunch L) 
     CA_ATTN_LDS_DONE();
     CA_ATTN_SYNC();
     if (active) {
-      __builtin_amdgcn_s_setprio(1);
+      CA_PRIO_HI();
       CA_ATTN_STREAM(0, 16, t, t)
-      __builtin_amdgcn_s_setprio(0);
+      CA_PRIO_LO();
     }
     CA_ATTN_SYNC();
   }

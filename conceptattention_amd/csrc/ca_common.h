@@ -23,6 +23,25 @@ __device__ __forceinline__ void ca_glds16(const void *gsrc, void *lds_wave_base)
   __builtin_amdgcn_global_load_lds((ca_gptr)gsrc, (ca_lptr)lds_wave_base, 16, 0, 0);
 }
 
+// The same copy issued from inline asm: hipcc then neither counts it in its own s_waitcnt bookkeeping
+// nor orders later LDS reads behind it (with the builtin it drains vmcnt(0) before the next
+// ds_read_b64_tr_b16, i.e. right after the DMA was issued).  The caller owns the wait: a counted
+// `s_waitcnt vmcnt(N)` and a barrier before any wave reads the bytes.  lds_wave_base must be
+// wave-uniform; M0 is saved and restored inside the statement (it is compiler-reserved).
+__device__ __forceinline__ void ca_glds16_asm(const void *gsrc, void *lds_wave_base) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ca_lptr)lds_wave_base);
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(dst)
+      : "memory");
+}
+
 __device__ __forceinline__ float ca_bf2f(bf16 x) { return (float)x; }
 
 // pack two floats into one dword of 2 x bf16 (RNE; hipcc emits v_cvt_pk_bf16_f32)
