@@ -117,16 +117,16 @@ def main():
     Lp = (args.size // 16) ** 2
     pipe = ConceptAttentionFluxPipeline(args.model, device=dev, weights="synthetic", weight_seed=0)
     layer_indices = list(range(15, 19))
-    n_items = world * (args.warmup + args.steps)
+    n_timed = world * args.steps  # timed work items 0..n_timed-1, item i on rank i % world
 
     # every work item's inputs are generated and made resident in HBM before timing
     def item_inputs(j):
         inp = synthetic_inputs(p, args.size, args.size, T, C, seed=1000 + j, device="cpu", dtype=torch.bfloat16)
         return {k: inp[k].to(dev) for k in ("latent", "txt", "vec", "concepts")}
 
-    my_items = D.shard_items(n_items, rank, world)
-    warm_items, timed_items = my_items[: args.warmup], my_items[args.warmup:]
-    inputs = {j: item_inputs(j) for j in my_items}
+    timed_items = D.shard_items(n_timed, rank, world)
+    warm_items = [n_timed + rank * args.warmup + i for i in range(args.warmup)]
+    inputs = {j: item_inputs(j) for j in timed_items + warm_items}
 
     def run_item(j):
         i = inputs[j]
@@ -160,22 +160,15 @@ def main():
             ops.set_gemm_hook(hook)
         local_maps.append(run_item(j))
     ops.set_gemm_hook(None)
-    local_maps = torch.stack(local_maps) if local_maps else torch.zeros(0, 2, C, args.size // 16, args.size // 16, device=dev)
-    # the one collective of the job: gather the small fp32 maps of all ranks (RCCL over xGMI)
-    timed_global = sorted(j for r in range(world) for j in D.shard_items(n_items, r, world)[args.warmup:])
-    if world > 1:
-        per = len(timed_items)
-        out = torch.empty((world, per) + tuple(local_maps.shape[1:]), device=dev)
-        torch.distributed.all_gather_into_tensor(out.view(world * per, *local_maps.shape[1:]), local_maps)
-        all_maps = out.view(world * per, *local_maps.shape[1:])
-    else:
-        all_maps = local_maps
+    local_maps = torch.stack(local_maps)
+    # the one collective of the job: gather the small fp32 maps of all ranks in item order (RCCL over xGMI)
+    all_maps = D.gather_heatmaps(local_maps, n_timed, rank, world)
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
 
-    calls = len(timed_global)
+    calls = n_timed
     maps_ok = bool(torch.isfinite(all_maps).all().item()) and abs(all_maps[:, 0].sum(1).mean().item() - 1.0) < 1e-3
 
     if rank == 0:
@@ -202,6 +195,17 @@ def main():
                         share_of_that_step=sec / (elapsed / max(len(timed_items), 1)))
         else:
             roof.update(kernel="whole path", achieved=path_tflops)
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside the process,
+        # so this is the rocprofv3 FETCH_SIZE/WRITE_SIZE measurement of this same command, committed
+        # under profiles/ (method and the gfx950 x2 FETCH_SIZE correction are recorded in the file)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
+            key = roof.get("kernel", "").split(" ")[0]
+            if key in pmc:
+                roof["traffic"] = pmc[key]["bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)"
+        except (OSError, KeyError, ValueError):
+            pass
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["path_achieved"] = path_tflops
         roof["path_frac"] = path_tflops / MFMA_BF16_PEAK_TFLOPS
