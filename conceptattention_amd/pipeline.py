@@ -80,6 +80,8 @@ class ConceptAttentionFluxPipeline:
         self.is_schnell = model_name == "flux-schnell"
         self.params = params if params is not None else configs[model_name]
         self.model = HipFluxDiT(self.params, self.device)
+        self._replicas = [self.model]  # activation sets that share self.model's weights (one per stream)
+        self._streams = []
         if isinstance(weights, str) and weights == "synthetic":
             self.model.weights.init_synthetic(weight_seed)
         elif isinstance(weights, str):
@@ -144,8 +146,60 @@ class ConceptAttentionFluxPipeline:
         return self._finish(image, concept_heatmaps, cross_attention_maps, return_pil_heatmaps, cmap)
 
     @torch.no_grad()
+    def generate_many_on_device(self, items, n_streams: int = 2, **kw):
+        """Throughput mode: independent work items (dicts with latent/txt/vec/concepts) are kept
+        ``n_streams`` at a time in flight on separate HIP streams of this GPU, each with its own
+        activation set and the shared weights, launches interleaved per diffusion step.  While one
+        item's kernel runs a partial last wave of workgroups (attention: 408 workgroups on 256 CUs,
+        several GEMMs likewise), the idle CUs take the other item's workgroups.  Results are
+        identical to ``generate_on_device`` item by item.  Returns [(img, heat, cross), ...]."""
+        n_streams = max(1, min(n_streams, len(items)))
+        while len(self._replicas) < n_streams:
+            self._replicas.append(HipFluxDiT(self.params, self.device, weights=self.model.weights))
+        while len(self._streams) < n_streams:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        cur = torch.cuda.current_stream(self.device)
+        results = [None] * len(items)
+        for g0 in range(0, len(items), n_streams):
+            group = list(range(g0, min(g0 + n_streams, len(items))))
+            gens = {}
+            for slot, i in enumerate(group):
+                st = self._streams[slot]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    it = items[i]
+                    gens[i] = self._generate_steps(self._replicas[slot], it["latent"], it["txt"], it["vec"],
+                                                   it["concepts"], **kw)
+            alive = dict(gens)
+            while alive:
+                for slot, i in enumerate(group):
+                    if i not in alive:
+                        continue
+                    with torch.cuda.stream(self._streams[slot]):
+                        try:
+                            next(alive[i])
+                        except StopIteration as stop:
+                            results[i] = stop.value
+                            del alive[i]
+            for slot, i in enumerate(group):
+                cur.wait_stream(self._streams[slot])
+                for t in results[i]:  # allocated on the side stream, consumed on the caller's stream
+                    t.record_stream(cur)
+        return results
+
+    @torch.no_grad()
     def generate_on_device(self, latent, txt, vec, concept_embeddings, layer_indices=list(range(15, 19)),
                            num_inference_steps: int = 4, guidance: float = 0.0, timesteps=None, fused: bool = True):
+        gen = self._generate_steps(self.model, latent, txt, vec, concept_embeddings, layer_indices,
+                                   num_inference_steps, guidance, timesteps, fused)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as stop:
+                return stop.value
+
+    def _generate_steps(self, model, latent, txt, vec, concept_embeddings, layer_indices=list(range(15, 19)),
+                        num_inference_steps: int = 4, guidance: float = 0.0, timesteps=None, fused: bool = True):
         """The device-resident core of generate_image: latent (1,16,h/8,w/8), txt (1,T,4096),
         vec (1,768), concept_embeddings (1,C,4096) already in HBM -> (final latent tokens,
         concept heat maps fp32 [1,C,side,side], cross-attention maps fp32 [1,C,side,side]) on the
@@ -168,14 +222,15 @@ class ConceptAttentionFluxPipeline:
             req = HeatmapRequest(tuple(ls), 1.0 / (len(ts) * len(ls)),
                                  torch.zeros(C, n_patches, device=self.device),
                                  torch.zeros(C, n_patches, device=self.device))
-            img, _, _ = sampling.denoise(self.model, **inp, timesteps=schedule, guidance=guidance,
-                                         concepts=con, concept_ids=con_ids, concept_vec=con_vec,
-                                         return_intermediate_images=False, return_vectors=False,
-                                         heatmaps=req, heatmap_timesteps=ts)
+            img, _, _ = yield from sampling.denoise_steps(
+                model, **inp, timesteps=schedule, guidance=guidance, concepts=con, concept_ids=con_ids,
+                concept_vec=con_vec, return_intermediate_images=False, return_vectors=False, heatmaps=req,
+                heatmap_timesteps=ts)
             side = int(round(n_patches ** 0.5))
             return img, req.out_space.view(1, C, side, side), req.cross_space.view(1, C, side, side)
-        img, _, d = sampling.denoise(self.model, **inp, timesteps=schedule, guidance=guidance, concepts=con,
-                                     concept_ids=con_ids, concept_vec=con_vec, return_intermediate_images=False)
+        img, _, d = yield from sampling.denoise_steps(
+            model, **inp, timesteps=schedule, guidance=guidance, concepts=con, concept_ids=con_ids,
+            concept_vec=con_vec, return_intermediate_images=False)
         cross_attention_maps = compute_heatmaps_from_vectors(
             d["cross_attention_image_vectors"], d["cross_attention_concept_vectors"],
             layer_indices=layer_indices, timesteps=timesteps)

@@ -97,6 +97,22 @@ def denoise(model, img, img_ids, txt, txt_ids, vec, timesteps: list[float], guid
     each dict entry stacked over time.  HIP-path extras: ``return_vectors=False`` +
     ``heatmaps``/``heatmap_timesteps`` accumulate the concept maps inside the model call for the
     selected (step, layer) pairs instead of stacking the vectors."""
+    gen = denoise_steps(model, img, img_ids, txt, txt_ids, vec, timesteps, guidance, concepts, concept_ids,
+                        concept_vec, return_intermediate_images, joint_attention_kwargs, return_vectors, heatmaps,
+                        heatmap_timesteps)
+    while True:
+        try:
+            next(gen)
+        except StopIteration as stop:
+            return stop.value
+
+
+def denoise_steps(model, img, img_ids, txt, txt_ids, vec, timesteps, guidance=4.0, concepts=None, concept_ids=None,
+                  concept_vec=None, return_intermediate_images=True, joint_attention_kwargs=None,
+                  return_vectors=True, heatmaps=None, heatmap_timesteps=None):
+    """Generator form of ``denoise``: yields after the launches of each diffusion step have been
+    enqueued (nothing is synchronised), so a caller can interleave several independent work items on
+    different HIP streams; the generator's return value is denoise's (img, intermediates, dict)."""
     img = img.to(torch.bfloat16).contiguous().clone()
     intermediates = [img.clone()] if return_intermediate_images else []
     out = {k: [] for k in DICT_KEYS} if return_vectors else {}
@@ -118,5 +134,6 @@ def denoise(model, img, img_ids, txt, txt_ids, vec, timesteps: list[float], guid
             intermediates.append(img.clone())
         for k in out:
             out[k].append(d[k])
+        yield it
     out = {k: torch.stack(v, 0) for k, v in out.items()}
     return img, intermediates, out

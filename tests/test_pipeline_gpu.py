@@ -44,6 +44,23 @@ def test_generate_image_api_and_fused_equals_stacked(pipe):
     assert np.abs(d.concept_heatmaps - e.concept_heatmaps).max() < 2e-3
 
 
+def test_two_streams_equal_sequential(pipe):
+    """Throughput mode (independent items on separate HIP streams, shared weights) is bit-identical
+    to running the items one after the other."""
+    from conceptattention_amd.weights import synthetic_inputs
+    items = []
+    for j in range(3):
+        inp = synthetic_inputs(pipe.params, 256, 256, 8, 3, seed=50 + j, dtype=torch.bfloat16)
+        items.append({k: inp[k].to(DEV) for k in ("latent", "txt", "vec", "concepts")})
+    kw = dict(layer_indices=[0, 1], num_inference_steps=2)
+    seq = [pipe.generate_on_device(i["latent"], i["txt"], i["vec"], i["concepts"], **kw) for i in items]
+    par = pipe.generate_many_on_device(items, n_streams=2, **kw)
+    torch.cuda.synchronize()
+    for a, b in zip(seq, par):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_generate_image_argument_checks(pipe):
     with pytest.raises(AssertionError):
         pipe.generate_image("p", ["a"], width=256, height=128)
