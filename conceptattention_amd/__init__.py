@@ -14,6 +14,9 @@ def __getattr__(name):  # lazy: keep `import conceptattention_amd` light for hos
     if name in ("HipFluxDiT", "FluxWeights", "HeatmapRequest"):
         from . import flux_dit
         return getattr(flux_dit, name)
+    if name in ("FluxGenerator", "load_flow_model"):
+        from . import image_generator
+        return getattr(image_generator, name)
     if name == "compute_heatmaps_from_vectors":
         from .heatmaps import compute_heatmaps_from_vectors
         return compute_heatmaps_from_vectors

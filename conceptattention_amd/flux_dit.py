@@ -115,6 +115,12 @@ class HeatmapRequest:
     weight: float                 # 1 / (|timesteps| * |layers|)
     out_space: torch.Tensor       # fp32 [C, L] accumulator (output-space maps)
     cross_space: torch.Tensor     # fp32 [C, L] accumulator (cross-attention-space maps)
+    # optional per-layer tables [len(layer_indices), C, L] (row i = layer_indices[i]), accumulated with
+    # per_layer_weight: the per-layer x per-noise-level extraction of
+    # experiments/per_layer_segmentation/test_segmentations_per_layer.py:104-114 without the vector stacks
+    per_layer_out: Optional[torch.Tensor] = None
+    per_layer_cross: Optional[torch.Tensor] = None
+    per_layer_weight: float = 1.0
 
 
 class HipFluxDiT:
@@ -190,8 +196,15 @@ class HipFluxDiT:
     def _rope_table(self, img_ids, txt_ids, concept_ids, C, T):
         """(cos, sin) per row in [concept | text | image] order.  rope(): angles in float64,
         stored fp32 (flux/math.py:15-22); EmbedND concatenates the axes (layers.py:18-25)."""
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (img_ids, txt_ids, concept_ids))
-        if self._rope_key == key:
+        def ver(t):  # inference-mode tensors have no version counter
+            try:
+                return t._version
+            except RuntimeError:
+                return -1
+        key = tuple((t.data_ptr(), ver(t), tuple(t.shape)) for t in (img_ids, txt_ids, concept_ids))
+        if any(k[1] < 0 for k in key):
+            key = None  # cannot prove the ids are unchanged: recompute
+        if key is not None and self._rope_key == key:
             return
         ids = torch.cat((concept_ids[0], txt_ids[0], img_ids[0]), 0).to(self.device, torch.float64)
         col = 0
@@ -422,10 +435,13 @@ class HipFluxDiT:
             # output space: the C concept rows come from the fp32 copy the attention kernel wrote
             # (their bf16 rounding, multiplied by the large component all attention outputs share,
             # is the dominant heat-map error otherwise -- DESIGN.md "tolerance")
-            for img_vec, con_vec, acc in ((ATT[CT:], self.ATT32[:C], heatmaps.out_space),
-                                          (QPRE[CT:], QPRE[:C], heatmaps.cross_space)):
+            li = heatmaps.layer_indices.index(layer)
+            for img_vec, con_vec, acc, table in ((ATT[CT:], self.ATT32[:C], heatmaps.out_space, heatmaps.per_layer_out),
+                                                 (QPRE[CT:], QPRE[:C], heatmaps.cross_space, heatmaps.per_layer_cross)):
                 ops.heatmap_logits(img_vec, con_vec, self.LOGITS[:C])
                 ops.heatmap_softmax_accumulate(self.LOGITS[:C], acc, heatmaps.weight)
+                if table is not None:
+                    ops.heatmap_softmax_accumulate(self.LOGITS[:C], table[li], heatmaps.per_layer_weight)
         if return_vectors:
             H = self.hidden_size
             out["output_space_concept_vectors"].append(ATT[:C].clone()[None])

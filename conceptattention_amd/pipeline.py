@@ -79,29 +79,21 @@ class ConceptAttentionFluxPipeline:
         self.device = torch.device(device)
         self.is_schnell = model_name == "flux-schnell"
         self.params = params if params is not None else configs[model_name]
-        self.model = HipFluxDiT(self.params, self.device)
+        # the generator owns model / encoders / autoencoder, as in the reference (:104-113)
+        from .image_generator import FluxGenerator
+        self.flux_generator = FluxGenerator(model_name=model_name, offload=offload_model, device=self.device,
+                                            weights=weights, weight_seed=weight_seed, text_encoder=text_encoder,
+                                            autoencoder=autoencoder, params=self.params,
+                                            n_text_tokens=n_text_tokens)
+        self.model = self.flux_generator.model
         self._replicas = [self.model]  # activation sets that share self.model's weights (one per stream)
         self._streams = []
-        if isinstance(weights, str) and weights == "synthetic":
-            self.model.weights.init_synthetic(weight_seed)
-        elif isinstance(weights, str):
-            from safetensors.torch import load_file
-            self.model.load_state_dict(load_file(weights, device=str(self.device)), strict=False)
-        elif weights is not None:
-            self.model.load_state_dict(weights, strict=False)
-        n_tok = n_text_tokens or T5_TOKENS.get(model_name, 256)
-        self.text_encoder = text_encoder or SyntheticTextEncoder(n_tok, self.params.context_in_dim,
-                                                                 self.params.vec_in_dim, self.device)
+        self.text_encoder = self.flux_generator.text_encoder
         self.autoencoder = autoencoder
 
     # ------------------------------------------------------------------ conditioning
     def _embed(self, prompt: str, concepts: Sequence[str]):
-        te = self.text_encoder
-        txt, vec = te.t5(prompt), te.clip(prompt)
-        # embed_concepts (concept_attention/utils.py:6-33): first T5 token of each concept
-        con = torch.stack([te.t5(c)[0, 0, :] for c in concepts]).unsqueeze(0)
-        con, con_ids, con_vec = sampling.concept_inputs(con, vec)
-        return txt, vec, con, con_ids, con_vec
+        return self.flux_generator.embed(prompt, concepts)
 
     def _finish(self, image, concept_heatmaps, cross_attention_maps, return_pil_heatmaps, cmap):
         concept_heatmaps = concept_heatmaps.to(torch.float32).detach().cpu().numpy()[0]
@@ -113,12 +105,7 @@ class ConceptAttentionFluxPipeline:
                                               cross_attention_maps=cross_attention_maps)
 
     def _decode(self, x: torch.Tensor, height: int, width: int):
-        lat = sampling.unpack(x.float(), height, width)
-        if self.autoencoder is None:
-            return lat[0].cpu().numpy()
-        import PIL.Image
-        img = self.autoencoder.decode(lat.to(torch.float32)).clamp(-1, 1)[0].permute(1, 2, 0)
-        return PIL.Image.fromarray((127.5 * (img + 1.0)).cpu().byte().numpy())
+        return self.flux_generator.decode(x, height, width)
 
     # ------------------------------------------------------------------ generate_image (:115-202)
     @torch.no_grad()
@@ -238,6 +225,47 @@ class ConceptAttentionFluxPipeline:
             d["output_space_image_vectors"], d["output_space_concept_vectors"],
             layer_indices=layer_indices, timesteps=timesteps)
         return img, concept_heatmaps, cross_attention_maps
+
+    # ------------------------------------------------------------------ per-layer x per-noise-level tables
+    @torch.no_grad()
+    def layer_noise_sweep_on_device(self, latent, txt, vec, concept_embeddings, noise_levels, num_steps: int = 50,
+                                    layer_indices=None, seed: int = 0, num_samples: int = 1,
+                                    rank: int = 0, world: int = 1):
+        """Concept maps per (noise level, double block): the workload of the reference's per-layer /
+        per-timestep segmentation sweeps (experiments/per_layer_segmentation/test_segmentations_per_layer.py:
+        104-114,164-189; experiments/per_timestep_segmentation/test_segmentations_per_time.py:75-104) without
+        ever materialising the vector stacks.  Every noise level is an independent forward of the 19 double
+        blocks from x = t*noise + (1-t)*latent (concept_attention/segmentation.py:85-113), so the levels shard
+        over ranks: this rank computes levels rank, rank+world, ...; rows of other ranks stay
+        zero and one all_reduce(sum) (distributed.allreduce_sum_) or all_gather completes the table.
+        noise_levels: indices into get_schedule(num_steps).  Returns (out_space, cross_space), each
+        fp32 [len(noise_levels), len(layer_indices), C, side, side]."""
+        layer_indices = list(range(self.params.depth)) if layer_indices is None else [int(l) for l in layer_indices]
+        latent = latent.to(self.device, torch.bfloat16)
+        n_patches = (latent.shape[-1] // 2) * (latent.shape[-2] // 2)
+        side = int(round(n_patches ** 0.5))
+        con, con_ids, con_vec = sampling.concept_inputs(concept_embeddings, vec)
+        C = con.shape[1]
+        schedule = sampling.get_schedule(num_steps, n_patches, shift=(not self.is_schnell))
+        nl, nlay = len(noise_levels), len(layer_indices)
+        out = torch.zeros(nl, nlay, C, n_patches, device=self.device)
+        cross = torch.zeros(nl, nlay, C, n_patches, device=self.device)
+        height, width = latent.shape[-2] * 8, latent.shape[-1] * 8
+        for li in range(rank, nl, world):
+            t = schedule[int(noise_levels[li])]
+            req = HeatmapRequest(tuple(layer_indices), 0.0, torch.zeros(C, n_patches, device=self.device),
+                                 torch.zeros(C, n_patches, device=self.device), per_layer_out=out[li],
+                                 per_layer_cross=cross[li], per_layer_weight=1.0 / num_samples)
+            for s_i in range(num_samples):
+                noise = sampling.get_noise(1, height, width, self.device, torch.bfloat16, seed + s_i)
+                x = (t * noise.float() + (1.0 - t) * latent.float()).to(torch.bfloat16)
+                inp = sampling.prepare_from_embeddings(x, txt, vec)
+                self.model(img=inp["img"], img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
+                           concepts=con, concept_ids=con_ids, concept_vec=con_vec, y=con_vec,
+                           timesteps=torch.full((1,), t, device=self.device),
+                           guidance=torch.zeros(1, device=self.device), stop_after_multimodal_attentions=True,
+                           return_vectors=False, heatmaps=req)
+        return out.view(nl, nlay, C, side, side), cross.view(nl, nlay, C, side, side)
 
     # ------------------------------------------------------------------ encode_image (:204-357)
     @torch.no_grad()

@@ -14,6 +14,7 @@ Fixtures
   tiny_ablation.npz                 joint_attention_kwargs branches of the double block
   block_full.npz                    ONE full-size double block (H=3072, L=4096, T=256, C=4)
   single_full.npz                   ONE full-size single block
+  block_full_dev.npz                ONE full-size double block at the flux-dev token counts (T=512, C=8)
   heatmap_kat.npz                   compute_heatmaps_from_vectors known answers (softmax branch)
   sampler.npz                       get_schedule / prepare-patchify / unpack / denoise (tiny, 2 steps)
 """
@@ -204,6 +205,41 @@ def full_blocks(ref, out_dir):
     print("single_full done")
 
 
+def full_block_dev(ref, out_dir):
+    """Full-size double block at the flux-dev token counts (BASELINE.json configs[2]): T=512, C=8."""
+    from conceptattention_amd.params import FluxParams
+    from conceptattention_amd.weights import synthetic_state_dict
+    from oracle.full_block_case import full_block_inputs
+    from concept_attention.flux.src.flux.modules.layers import EmbedND
+    p = FluxParams(guidance_embed=True)
+    H, NH = p.hidden_size, p.num_heads
+    case = full_block_inputs(p, T=512, C=8, seed=8)
+    sd = synthetic_state_dict(p, seed=0, prefix="double_blocks.0.")
+    sd = {k[len("double_blocks.0."):]: v.bfloat16().float() for k, v in sd.items()}
+    blk = ref["ModifiedDoubleStreamBlock"](H, NH, mlp_ratio=p.mlp_ratio, qkv_bias=True).eval()
+    blk.load_state_dict(sd, strict=True)
+    emb = EmbedND(dim=128, theta=p.theta, axes_dim=list(p.axes_dim))
+    pe = emb(torch.cat((case["txt_ids"], case["img_ids"]), 1))
+    cpe = emb(torch.cat((case["concept_ids"], case["img_ids"]), 1))
+    with torch.no_grad():
+        img, txt, con, d = blk(img=case["img"], txt=case["txt"], vec=case["vec"], pe=pe,
+                               concepts=case["concepts"], concept_vec=case["concept_vec"], concept_pe=cpe)
+    st = {k: v[None, None] for k, v in d.items()}
+    fn = ref["compute_heatmaps_from_vectors"]
+    hm_out = fn(st["output_space_image_vectors"], st["output_space_concept_vectors"], layer_indices=[0],
+                timesteps=[0], softmax=True)
+    hm_cross = fn(st["cross_attention_image_vectors"], st["cross_attention_concept_vectors"], layer_indices=[0],
+                  timesteps=[0], softmax=True)
+    rows = case["sample_rows"]
+    np.savez_compressed(os.path.join(out_dir, "block_full_dev.npz"),
+                        heatmap_output_space=hm_out.numpy(), heatmap_cross_attention=hm_cross.numpy(),
+                        concept_attn=d["output_space_concept_vectors"].numpy(),
+                        img_attn_rows=d["output_space_image_vectors"][0, rows].numpy(),
+                        img_out_rows=img[0, rows].numpy(), txt_out=txt[0, ::16].numpy(), concepts_out=con.numpy(),
+                        sample_rows=rows.numpy())
+    print("block_full_dev heat range", hm_out.min().item(), hm_out.max().item())
+
+
 def heatmap_kat(ref, out_dir):
     fn = ref["compute_heatmaps_from_vectors"]
     g = torch.Generator().manual_seed(11)
@@ -272,7 +308,7 @@ def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     ref = _import_reference()
-    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "full"]
+    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "full", "fulldev"]
     if "tiny" in which:
         tiny_model(ref, out_dir, False, "tiny_schnell.npz")
         tiny_model(ref, out_dir, True, "tiny_dev.npz")
@@ -284,6 +320,8 @@ def main():
         sampler(ref, out_dir)
     if "full" in which:
         full_blocks(ref, out_dir)
+    if "fulldev" in which:
+        full_block_dev(ref, out_dir)
 
 
 if __name__ == "__main__":

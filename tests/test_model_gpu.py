@@ -150,16 +150,16 @@ def test_argument_errors_match_reference():
         m.load_state_dict({"nope": torch.zeros(1)})
 
 
-def _full_block_model(prefix_kind):
+def _full_block_model(prefix_kind, T=256, C=4, seed=7):
     """A HipFluxDiT holding ONE full-size block (H=3072) with the golden case's weights."""
     from oracle.full_block_case import full_block_inputs
     p = FluxParams(depth=1 if prefix_kind == "double" else 0, depth_single_blocks=0 if prefix_kind == "double" else 1)
-    case = full_block_inputs(p)
+    case = full_block_inputs(p, T=T, C=C, seed=seed)
     m = HipFluxDiT(p, DEV)
     pref = "double_blocks.0." if prefix_kind == "double" else "single_blocks.0."
     sd = synthetic_state_dict(p, seed=0, prefix=pref)
     m.load_state_dict(sd, strict=False)
-    L, T, C = 4096, 256, 4
+    L = 4096
     m._workspace(L, T, C)
     m._rope_table(case["img_ids"], case["txt_ids"], case["concept_ids"], C, T)
     m.X[:C].copy_(case["concepts"][0])
@@ -220,3 +220,25 @@ def test_full_size_single_block_vs_reference_golden(golden):
     m._single_block(0, C, T, L)
     rows = torch.from_numpy(g["sample_rows"]).to(DEV)
     assert maxabs(m.X[C:][rows], g["out_rows"]) < 6e-2
+
+
+def test_full_size_double_block_dev_token_counts(golden):
+    """flux-dev token counts (T=512, C=8: two passes of the 4-concept logits kernel, 8 concept query
+    rows in the attention launch) against the reference's golden for that case."""
+    g = golden("block_full_dev.npz")
+    m, case, (L, T, C) = _full_block_model("double", T=512, C=8, seed=8)
+    req = HeatmapRequest((0,), 1.0, torch.zeros(C, L, device=DEV), torch.zeros(C, L, device=DEV))
+    m._double_block(0, C, T, L, None, None, False, req)
+    rows = torch.from_numpy(g["sample_rows"]).to(DEV)
+    CT = C + T
+    assert maxabs(m.ATT32[:C], g["concept_attn"][0]) < 1e-3   # fp32 copy: no output rounding
+    assert maxabs(m.ATT[CT:][rows], g["img_attn_rows"]) < 8e-3
+    hm = req.out_space.view(C, 64, 64)
+    assert maxabs(hm, g["heatmap_output_space"][0]) < 1e-3
+    assert abs(hm.sum(0) - 1).max().item() < 1e-5
+    cm = req.cross_space.view(C, 64, 64).cpu()
+    ref_cm = torch.from_numpy(g["heatmap_cross_attention"][0])
+    assert maxabs(cm, ref_cm) < 2e-2 and (cm.argmax(0) == ref_cm.argmax(0)).float().mean().item() > 0.985
+    assert maxabs(m.X[CT:][rows], g["img_out_rows"]) < 6e-2
+    assert maxabs(m.X[C:CT][::16], g["txt_out"]) < 6e-2
+    assert maxabs(m.X[:C], g["concepts_out"][0]) < 6e-2

@@ -145,3 +145,22 @@ def test_full_size_blocks(golden):
     y = O.single_block(sds, "single_blocks.0.", p.num_heads, torch.cat((case["txt"], case["img"]), 1),
                        case["vec"], rope_ti)
     assert _maxabs(y[0, _t(gs["sample_rows"])], gs["out_rows"]) < 2e-4
+
+
+def test_full_size_block_dev_token_counts(golden):
+    """T=512 text tokens, C=8 concepts (BASELINE.json configs[2] geometry), one full-size double block."""
+    from oracle.full_block_case import full_block_inputs
+    g = golden("block_full_dev.npz")
+    p = FluxParams(guidance_embed=True)
+    case = full_block_inputs(p, T=512, C=8, seed=8)
+    sd = {k: v.bfloat16().float() for k, v in synthetic_state_dict(p, seed=0, prefix="double_blocks.0.").items()}
+    rope_ti = O.rope_cos_sin(torch.cat((case["txt_ids"][0], case["img_ids"][0])), p.axes_dim, p.theta)
+    rope_ci = O.rope_cos_sin(torch.cat((case["concept_ids"][0], case["img_ids"][0])), p.axes_dim, p.theta)
+    img, txt, con, d = O.double_block(sd, "double_blocks.0.", p.num_heads, case["img"], case["txt"], case["vec"],
+                                      rope_ti, case["concepts"], case["concept_vec"], rope_ci)
+    rows = _t(g["sample_rows"])
+    assert _maxabs(d["output_space_concept_vectors"], g["concept_attn"]) < 1e-5
+    assert _maxabs(img[0, rows], g["img_out_rows"]) < 2e-4
+    st = {k: v[None, None] for k, v in d.items()}
+    hm = O.compute_heatmaps(st["output_space_image_vectors"], st["output_space_concept_vectors"], [0], [0])
+    assert hm.shape == (1, 8, 64, 64) and _maxabs(hm, g["heatmap_output_space"]) < 1e-5

@@ -44,6 +44,27 @@ def test_generate_image_api_and_fused_equals_stacked(pipe):
     assert np.abs(d.concept_heatmaps - e.concept_heatmaps).max() < 2e-3
 
 
+def test_flux_generator_contract(pipe):
+    """FluxGenerator.generate_image returns (image, dict) with the reference's four keys stacked over
+    [steps, double blocks, batch, ...] (image_generator.py:87-205, sampling.py:149-150); feeding that dict
+    to compute_heatmaps_from_vectors reproduces the pipeline's stacked-path maps."""
+    gen = pipe.flux_generator
+    lat = torch.randn(1, 16, 32, 32, generator=torch.Generator().manual_seed(1)).to(DEV, torch.bfloat16)
+    img, d = gen.generate_image(width=256, height=256, num_steps=2, guidance=0.0, seed=0, prompt="a cat",
+                                concepts=["cat", "sky"], latent=lat)
+    nb = pipe.params.depth
+    assert d["output_space_image_vectors"].shape == (2, nb, 1, 256, 256)
+    assert d["output_space_concept_vectors"].shape == (2, nb, 1, 2, 256)
+    assert d["cross_attention_image_vectors"].shape == (2, nb, 1, 2, 256, 128)
+    assert d["cross_attention_concept_vectors"].shape == (2, nb, 1, 2, 2, 128)
+    assert img.shape == (16, 32, 32)
+    hm = compute_heatmaps_from_vectors(d["output_space_image_vectors"], d["output_space_concept_vectors"],
+                                       layer_indices=[0, 1], timesteps=[0, 1])
+    out = pipe.generate_image("a cat", ["cat", "sky"], width=256, height=256, layer_indices=[0, 1],
+                              num_inference_steps=2, latent=lat, fused=False, return_pil_heatmaps=False)
+    assert np.abs(hm[0].cpu().numpy() - out.concept_heatmaps).max() < 1e-6
+
+
 def test_two_streams_equal_sequential(pipe):
     """Throughput mode (independent items on separate HIP streams, shared weights) is bit-identical
     to running the items one after the other."""
@@ -80,6 +101,37 @@ def test_encode_image_runs_double_blocks_only(pipe):
     assert np.abs(out.concept_heatmaps.sum(0) - 1).max() < 1e-5
     with pytest.raises(ValueError):
         pipe.encode_image(object(), ["x"], width=256, height=256, layer_indices=[0])
+
+
+def test_layer_noise_sweep_matches_oracle(pipe):
+    """Per-(noise level, layer) tables: every entry equals the oracle's map for that single forward, and
+    sharding the levels over 2 'ranks' then summing reproduces the unsharded table."""
+    from conceptattention_amd import sampling
+    from conceptattention_amd.weights import synthetic_inputs
+    p = pipe.params
+    inp = synthetic_inputs(p, 256, 256, 8, 3, seed=9, dtype=torch.bfloat16)
+    x = {k: inp[k].to(DEV) for k in ("latent", "txt", "vec", "concepts")}
+    levels = [1, 3]
+    out, cross = pipe.layer_noise_sweep_on_device(x["latent"], x["txt"], x["vec"], x["concepts"], levels,
+                                                  num_steps=4, seed=5)
+    assert out.shape == (2, p.depth, 3, 16, 16)
+    parts = [pipe.layer_noise_sweep_on_device(x["latent"], x["txt"], x["vec"], x["concepts"], levels, num_steps=4,
+                                              seed=5, rank=r, world=2)[0] for r in range(2)]
+    assert torch.equal(parts[0] + parts[1], out)
+    # oracle for level index 1 (schedule[3]) with the same noise tensor
+    sd = {k: v.float().cpu() for k, v in pipe.model.state_dict().items()}
+    sched = sampling.get_schedule(4, 256, shift=False)
+    t = sched[3]
+    noise = sampling.get_noise(1, 256, 256, torch.device(DEV), torch.bfloat16, 5)
+    xn = (t * noise.float() + (1.0 - t) * x["latent"].float()).to(torch.bfloat16).float().cpu()
+    f = {k: v.float().cpu() for k, v in inp.items() if v.is_floating_point()}
+    _, d = O.dit_forward(sd, p, O.patchify(xn), inp["img_ids"], f["txt"], inp["txt_ids"], f["concepts"],
+                         inp["concept_ids"], f["concept_vec"], torch.tensor([t]), f["concept_vec"],
+                         stop_after_multimodal_attentions=True)
+    for layer in range(p.depth):
+        st = {k: v[None] for k, v in d.items()}
+        ref = O.compute_heatmaps(st["output_space_image_vectors"], st["output_space_concept_vectors"], [layer], [0])
+        assert (out[1, layer].cpu() - ref[0]).abs().max() < 3e-3, layer
 
 
 def test_heatmap_known_answers_through_hip(golden):
