@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconceptattn.so")
 
 CA_VERSION = 100
-EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU = 0, 1, 2, 3
+EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU, EPI_QKV_NORM_ROPE = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_256x256, TILE_256x192, TILE_256x128, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_PP_256x256, TILE_PP_256x128, TILE_PP_256x192 = 5, 6, 7
 MAX_SEGMENTS = 4
@@ -22,10 +22,11 @@ GEMM_MAX_PROBLEMS = 2
 class GemmProblem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
                 ("resid", C.c_void_p), ("gate", C.c_void_p), ("gate2", C.c_void_p), ("out2", C.c_void_p),
+                ("norm_q", C.c_void_p), ("norm_k", C.c_void_p), ("rope", C.c_void_p), ("q_prerope", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("ld2", C.c_int32), ("n_split", C.c_int32), ("gate_rows", C.c_int32),
-                ("epilogue", C.c_int32)]
+                ("epilogue", C.c_int32), ("ldp", C.c_int32)]
 
 
 class AttnProblem(C.Structure):

@@ -467,6 +467,81 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
   char *outb = (char *)P.out;
   int ldo = P.ldc;
   int col_shift = 0;
+  if constexpr (NL == 2 && NHI == 2) {
+    // ---- fused QK-RMSNorm + RoPE on the q and k thirds of a qkv projection (one head = one 128-column
+    // half of the tile).  Per row and head the sum of squares is reduced over the lane's 8 columns, the 4
+    // lane groups (shuffles) and the 4 column-waves (through LDS, which the main loop no longer uses).
+    if (epi == CA_EPI_QKV_NORM_ROPE && n0 < (P.n_split / 3) * 2) {
+      const int hd = P.n_split / 3;               // heads * 128
+      const bool is_q = n0 < hd;
+      const bf16 *nscale = (const bf16 *)(is_q ? P.norm_q : P.norm_k);
+      float *part = (float *)smem;                // [2 halves][256 rows][4 column-waves]
+      float x[8][2][8];
+      __syncthreads();  // every wave has retired its own LDS-DMA (vmcnt 0 above): the LDS is reusable
+#pragma unroll
+      for (int hn = 0; hn < 2; ++hn) {
+        const int nb = n0 + hn * 128 + wn * 32 + 8 * g;
+        float bias[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bias[t] = 0.f;
+        if (P.bias) {
+          const bf16x8 b8 = *(const bf16x8 *)((const bf16 *)P.bias + nb);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) bias[t] = (float)b8[t];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          float sq = 0.f;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = acc[mi][hn * 2 + j][r] + bias[4 * j + r];
+              x[mi][hn][4 * j + r] = v;
+              sq += v * v;
+            }
+          sq += __shfl_xor(sq, 16);
+          sq += __shfl_xor(sq, 32);
+          const int rl = (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
+          if (g == 0) part[(hn * 256 + rl) * 4 + wn] = sq;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int hn = 0; hn < 2; ++hn) {
+        const int cih = wn * 32 + 8 * g;           // column inside the head
+        const int head_col = (n0 - (is_q ? 0 : hd)) + hn * 128;  // first column of this head in its third
+        const bf16x8 s8 = *(const bf16x8 *)(nscale + cih);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int rl = (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
+          const int m = m0 + rl;
+          if (m >= M) continue;
+          const f32x4 p4 = *(const f32x4 *)(part + (hn * 256 + rl) * 4);
+          const float rrms = rsqrtf((p4[0] + p4[1] + p4[2] + p4[3]) * (1.0f / 128.0f) + 1e-6f);
+          float y[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) y[t] = x[mi][hn][t] * rrms * (float)s8[t];
+          if (is_q && P.q_prerope)
+            *(uint4 *)((bf16 *)P.q_prerope + (size_t)m * P.ldp + head_col + cih) =
+                make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+          const float *rp = P.rope + (size_t)m * 128 + cih;  // [64 pairs][cos,sin]; pairs cih/2 .. cih/2+3
+          const f32x4 r0 = *(const f32x4 *)rp, r1 = *(const f32x4 *)(rp + 4);
+          const float cs[4] = {r0[0], r0[2], r1[0], r1[2]}, sn[4] = {r0[1], r0[3], r1[1], r1[3]};
+          float z[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            z[2 * i] = cs[i] * y[2 * i] - sn[i] * y[2 * i + 1];
+            z[2 * i + 1] = sn[i] * y[2 * i] + cs[i] * y[2 * i + 1];
+          }
+          *(uint4 *)(outb + ((size_t)m * ldo + n0 + hn * 128 + cih) * 2) =
+              make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
+        }
+      }
+      return;
+    }
+  }
+  if (epi == CA_EPI_QKV_NORM_ROPE) epi = CA_EPI_SPLIT_GELU;  // v third: plain; columns past n_split: GELU -> out2
   if (epi == CA_EPI_SPLIT_GELU) {
     if (n0 >= P.n_split) {
       epi = CA_EPI_GELU_TANH;
@@ -615,6 +690,7 @@ int auto_tile(const ca_gemm_problem *p, int n) {
     for (int i = 0; i < n; ++i) {
       if (p[i].N % bn) ok = false;
       if (p[i].epilogue == CA_EPI_SPLIT_GELU && p[i].n_split % bn) ok = false;
+      if (p[i].epilogue == CA_EPI_QKV_NORM_ROPE && c.tile != CA_TILE_PP_256x256) ok = false;
       const long t = (long)((p[i].M + 255) / 256) * (p[i].N / bn);
       tiles += t;
       work += (double)t * p[i].K;
@@ -695,6 +771,17 @@ extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems,
         if (!p.resid || !p.gate || p.ldr % 8 || p.ldc < p.N || ((uintptr_t)p.resid & 15) ||
             ((uintptr_t)p.gate & 15) || ((uintptr_t)p.gate2 & 15) || (p.gate_rows < p.M && !p.gate2)) {
           ca_set_error("ca_gemm_bf16[%d]: GATE_RESIDUAL needs resid, gate (and gate2 when gate_rows < M), 16-byte aligned", i);
+          return CA_ERR_ARG;
+        }
+        break;
+      case CA_EPI_QKV_NORM_ROPE:
+        if (tile != CA_TILE_PP_256x256 || p.n_split <= 0 || p.n_split % 768 || p.n_split > p.N || !p.norm_q ||
+            !p.norm_k || !p.rope || (p.n_split < p.N && (!p.out2 || p.ld2 % 8 || p.ld2 < p.N - p.n_split)) ||
+            p.ldc < p.n_split || (p.q_prerope && (p.ldp % 8 || p.ldp < p.n_split / 3)) ||
+            (((uintptr_t)p.norm_q | (uintptr_t)p.norm_k | (uintptr_t)p.rope | (uintptr_t)p.q_prerope |
+              (uintptr_t)p.out2) & 15)) {
+          ca_set_error("ca_gemm_bf16[%d]: QKV_NORM_ROPE needs the 256x256 ping-pong tile, n_split = 3*heads*128 <= N, "
+                       "norm_q/norm_k/rope (16-byte aligned) and out2 when N > n_split", i);
           return CA_ERR_ARG;
         }
         break;

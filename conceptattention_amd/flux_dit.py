@@ -352,7 +352,7 @@ class HipFluxDiT:
     def _double_block(self, i, C, T, Li, joint_attention_kwargs=None, out=None, return_vectors=False,
                       heatmaps=None):
         """ModifiedDoubleStreamBlock.forward (modified_double_stream_block.py:69-204) on the
-        resident X rows [concepts | text | image]; 8 launches."""
+        resident X rows [concepts | text | image]; 7 launches."""
         p, W = self.params, self.weights
         H, NH = p.hidden_size, p.num_heads
         CT, n = C + T, C + T + Li
@@ -369,13 +369,17 @@ class HipFluxDiT:
         ops.ln_modulate(X, XM, [(C, self._mod(tm, 1, 0), self._mod(tm, 1, 1)),
                                 (CT, self._mod(tm, 0, 0), self._mod(tm, 0, 1)),
                                 (n, self._mod(im, 0, 0), self._mod(im, 0, 1))])
-        # K5: qkv projections, image stream + [concept|text] stream in one grouped launch
-        ops.gemm([ops.Gemm(XM[CT:], W[b + "img_attn.qkv.weight"], W.tensors.get(b + "img_attn.qkv.bias"), QKV[CT:]),
-                  ops.Gemm(XM[:CT], W[b + "txt_attn.qkv.weight"], W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:CT])])
-        # K6+K7: QK-RMSNorm then RoPE in place; pre-RoPE q kept for the cross-attention maps
-        ops.qknorm_rope(QKV, NH, [(CT, W[b + "txt_attn.norm.query_norm.scale"], W[b + "txt_attn.norm.key_norm.scale"]),
-                                  (n, W[b + "img_attn.norm.query_norm.scale"], W[b + "img_attn.norm.key_norm.scale"])],
-                        self.ROPE, q_prerope=self.QPRE if capture else None)
+        # K5+K6+K7: qkv projections (image stream + [concept|text] stream in one grouped launch) with
+        # QK-RMSNorm and RoPE fused into the epilogue; pre-RoPE q kept for the cross-attention maps
+        qpre = self.QPRE if capture else None
+        ops.gemm([ops.Gemm(XM[CT:], W[b + "img_attn.qkv.weight"], W.tensors.get(b + "img_attn.qkv.bias"), QKV[CT:],
+                           L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
+                           norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[CT:],
+                           q_prerope=None if qpre is None else qpre[CT:]),
+                  ops.Gemm(XM[:CT], W[b + "txt_attn.qkv.weight"], W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:CT],
+                           L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
+                           norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:CT],
+                           q_prerope=None if qpre is None else qpre[:CT])])
         # K8+K9: joint text+image attention and the concept rows in one launch
         probs = [ops.Attn(qs[C:], ATT[C:], ks[C:], vs[C:])]
         if C > 0:
@@ -411,17 +415,16 @@ class HipFluxDiT:
 
     def _single_block(self, i, C, T, Li):
         """ModifiedSingleStreamBlock.forward (modified_single_stream_block.py:43-56) on the
-        [text | image] rows; 5 launches."""
+        [text | image] rows; 4 launches."""
         p, W = self.params, self.weights
         H, NH = p.hidden_size, p.num_heads
         xs, xms, qkvs, CAT = self.X[C:], self.XM[C:], self.QKV[C:], self.CAT
         b = f"single_blocks.{i}."
         m = b + "modulation.lin"
         ops.ln_modulate(xs, xms, [(T + Li, self._mod(m, 0, 0), self._mod(m, 0, 1))])
-        ops.gemm([ops.Gemm(xms, W[b + "linear1.weight"], W[b + "linear1.bias"], qkvs, L.EPI_SPLIT_GELU,
-                           out2=CAT[:, H:], n_split=3 * H)])
-        ops.qknorm_rope(qkvs, NH, [(T + Li, W[b + "norm.query_norm.scale"], W[b + "norm.key_norm.scale"])],
-                        self.ROPE[C:])
+        ops.gemm([ops.Gemm(xms, W[b + "linear1.weight"], W[b + "linear1.bias"], qkvs, L.EPI_QKV_NORM_ROPE,
+                           out2=CAT[:, H:], n_split=3 * H, norm_q=W[b + "norm.query_norm.scale"],
+                           norm_k=W[b + "norm.key_norm.scale"], rope=self.ROPE[C:])])
         ops.attention([ops.Attn(qkvs[:, :H], CAT[:, :H], qkvs[:, H:2 * H], qkvs[:, 2 * H:])], NH)
         ops.gemm([ops.Gemm(CAT, W[b + "linear2.weight"], W[b + "linear2.bias"], xs, L.EPI_GATE_RESIDUAL,
                            resid=xs, gate=self._mod(m, 0, 2))])

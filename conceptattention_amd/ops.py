@@ -46,8 +46,12 @@ class Gemm:
     gate: Optional[torch.Tensor] = None   # [N] fp32
     gate2: Optional[torch.Tensor] = None  # [N] fp32 for rows >= gate_rows
     gate_rows: Optional[int] = None
-    out2: Optional[torch.Tensor] = None   # SPLIT_GELU second output [M,N-n_split]
+    out2: Optional[torch.Tensor] = None   # SPLIT_GELU / QKV_NORM_ROPE second output [M,N-n_split]
     n_split: int = 0
+    norm_q: Optional[torch.Tensor] = None  # QKV_NORM_ROPE: bf16 [128] scales, fp32 [M,64,2] rope table,
+    norm_k: Optional[torch.Tensor] = None  # optional bf16 [M, heads*128] pre-RoPE q output
+    rope: Optional[torch.Tensor] = None
+    q_prerope: Optional[torch.Tensor] = None
 
 
 def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
@@ -70,6 +74,19 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
             p.resid, p.ldr = _chk(g.resid, torch.bfloat16, "resid").data_ptr(), g.resid.stride(0)
             p.gate = _chk(g.gate, torch.float32, "gate").data_ptr()
             p.gate2 = _ptr(None if g.gate2 is None else _chk(g.gate2, torch.float32, "gate2"))
+        elif g.epilogue == L.EPI_QKV_NORM_ROPE:
+            if g.norm_q is None or g.norm_k is None or g.rope is None:
+                raise ValueError(f"gemm[{i}]: QKV_NORM_ROPE needs norm_q, norm_k, rope")
+            p.norm_q = _chk(g.norm_q, torch.bfloat16, "norm_q").data_ptr()
+            p.norm_k = _chk(g.norm_k, torch.bfloat16, "norm_k").data_ptr()
+            rope = _chk(g.rope, torch.float32, "rope")
+            if tuple(rope.shape) != (p.M, 64, 2) or not rope.is_contiguous():
+                raise ValueError(f"gemm[{i}]: rope must be contiguous [M,64,2]")
+            p.rope, p.n_split = rope.data_ptr(), g.n_split
+            if g.q_prerope is not None:
+                p.q_prerope, p.ldp = _chk(g.q_prerope, torch.bfloat16, "q_prerope").data_ptr(), g.q_prerope.stride(0)
+            if g.out2 is not None:
+                p.out2, p.ld2 = _chk(g.out2, torch.bfloat16, "out2").data_ptr(), g.out2.stride(0)
         elif g.epilogue == L.EPI_SPLIT_GELU:
             if g.out2 is None:
                 raise ValueError(f"gemm[{i}]: SPLIT_GELU needs out2")

@@ -57,9 +57,14 @@ enum {
   CA_EPI_BIAS = 0,          /* out = acc + bias */
   CA_EPI_GELU_TANH = 1,     /* out = gelu_tanh(acc + bias)          (mlp.0, :196)          */
   CA_EPI_GATE_RESIDUAL = 2, /* out = resid + gate[n]*(acc + bias)   (:194-202)             */
-  CA_EPI_SPLIT_GELU = 3     /* n <  n_split: out  = acc + bias                             */
+  CA_EPI_SPLIT_GELU = 3,    /* n <  n_split: out  = acc + bias                             */
                             /* n >= n_split: out2 = gelu_tanh(acc+bias), column n-n_split  */
                             /* (single block linear1 -> qkv | mlp, single_stream_block:49) */
+  CA_EPI_QKV_NORM_ROPE = 4  /* qkv projection with QKNorm + RoPE fused (256x256 ping-pong tile only):      */
+                            /* columns [0, n_split) are q|k|v thirds of heads*128 columns each;             */
+                            /* q, k: out = rope(rmsnorm(acc+bias) * norm_{q,k}), optional q_prerope store;   */
+                            /* v: out = acc + bias; columns >= n_split: out2 = gelu_tanh(acc+bias)           */
+                            /* (flux/modules/layers.py:63-84, flux/math.py:25-30, double_stream_block:189)  */
 };
 
 /* tile = block tile M x N; the PP ("ping-pong") kernels are the pipelined fast path */
@@ -76,12 +81,17 @@ typedef struct {
   const void *resid; /* bf16 [M,N], row stride ldr; GATE_RESIDUAL only; may alias out */
   const float *gate; /* fp32 [N]; GATE_RESIDUAL: gate for rows <  gate_rows */
   const float *gate2;/* fp32 [N]; GATE_RESIDUAL: gate for rows >= gate_rows (may be NULL if gate_rows >= M) */
-  void *out2;        /* bf16 [M,N-n_split], row stride ld2; SPLIT_GELU only */
+  void *out2;        /* bf16 [M,N-n_split], row stride ld2; SPLIT_GELU / QKV_NORM_ROPE tail */
+  const void *norm_q;/* bf16 [128] query_norm.scale; QKV_NORM_ROPE only */
+  const void *norm_k;/* bf16 [128] key_norm.scale */
+  const float *rope; /* fp32 [M,64,2] (cos,sin) for this problem's rows */
+  void *q_prerope;   /* optional bf16 [M, heads*128], row stride ldp: normalised pre-RoPE q */
   int32_t M, N, K;
   int32_t lda, ldw, ldc, ldr, ld2;
-  int32_t n_split;   /* SPLIT_GELU: multiple of the tile width */
+  int32_t n_split;   /* SPLIT_GELU: multiple of the tile width; QKV_NORM_ROPE: 3*heads*128 */
   int32_t gate_rows;
   int32_t epilogue;  /* CA_EPI_* */
+  int32_t ldp;       /* row stride of q_prerope */
 } ca_gemm_problem;
 
 int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile, ca_stream_t stream);

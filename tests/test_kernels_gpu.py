@@ -96,6 +96,42 @@ def test_gemm_grouped_two_problems(tile):
     close(o1, torch.nn.functional.gelu(a1.float() @ w1.float().t() + b1.float(), approximate="tanh"), atol=2e-2)
 
 
+@pytest.mark.parametrize("tail", [0, 512])
+def test_gemm_qkv_norm_rope_epilogue(tail):
+    """qkv projection with QK-RMSNorm + RoPE fused (and, for the single blocks, a GELU'd mlp tail):
+    compared with the oracle's fp32 rms_norm / apply_rope on the fp32 projection."""
+    from oracle import flux_oracle as O
+    nh, M, K = 2, 300, 192
+    Hd = nh * 128
+    N = 3 * Hd + tail
+    a, w, b = rnd(M, K), rnd(N, K, scale=0.1), rnd(N)
+    ids = torch.zeros(M, 3)
+    ids[20:, 1] = torch.arange(M - 20) // 16
+    ids[20:, 2] = torch.arange(M - 20) % 16
+    cos, sin = O.rope_cos_sin(ids, (16, 56, 56), 10000)
+    table = torch.stack((cos, sin), -1).contiguous().to(DEV)
+    nq, nk = (0.5 + torch.rand(128)).bfloat16().to(DEV), (0.5 + torch.rand(128)).bfloat16().to(DEV)
+    out = torch.zeros(M, 3 * Hd, device=DEV, dtype=torch.bfloat16)
+    pre = torch.zeros(M, Hd, device=DEV, dtype=torch.bfloat16)
+    out2 = torch.zeros(M, max(tail, 8), device=DEV, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(a, w, b, out, L.EPI_QKV_NORM_ROPE, n_split=3 * Hd, norm_q=nq, norm_k=nk, rope=table,
+                       q_prerope=pre, out2=out2 if tail else None)])
+    lin = (a.float() @ w.float().t() + b.float()).cpu()
+    qkv = lin[:, :3 * Hd].view(M, 3, nh, 128)
+    for which, sc in ((0, nq), (1, nk)):
+        normed = O.rms_norm(qkv[:, which], sc.float().cpu())
+        if which == 0:
+            close(pre.cpu(), normed.reshape(M, -1), atol=1e-2)
+        roped = O.apply_rope(normed.permute(1, 0, 2)[None], cos, sin)[0].permute(1, 0, 2)
+        close(out.cpu().view(M, 3, nh, 128)[:, which], roped, atol=1e-2)
+    close(out.cpu().view(M, 3, nh, 128)[:, 2], qkv[:, 2], atol=2e-2)
+    if tail:
+        close(out2.cpu(), torch.nn.functional.gelu(lin[:, 3 * Hd:], approximate="tanh"), atol=2e-2)
+    with pytest.raises(ValueError):  # only the 256x256 ping-pong tile carries this epilogue
+        ops.gemm([ops.Gemm(a, w, b, out, L.EPI_QKV_NORM_ROPE, n_split=3 * Hd, norm_q=nq, norm_k=nk, rope=table,
+                           out2=out2 if tail else None)], L.TILE_PP_256x128)
+
+
 def test_gemm_rejects_bad_arguments():
     a, w = rnd(16, 100), rnd(256, 100)
     with pytest.raises(ValueError):

@@ -54,7 +54,7 @@ def bench_attn(n, nh=24, C=0):
     print(f"attn n={n} heads={nh} C={C}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     print(torch.cuda.get_device_name(0))
     PP, PP1, PP2 = L.TILE_PP_256x256, L.TILE_PP_256x128, L.TILE_PP_256x192
     for tile in (PP, PP2, PP1):
@@ -97,3 +97,28 @@ if __name__ == "__main__":
     acc = torch.zeros(4, 4096, device=dev)
     t = timeit(lambda: (ops.heatmap_logits(img, con, lg), ops.heatmap_softmax_accumulate(lg, acc, 1.0)))
     print(f"heatmap 4096x3072 C=4: {t*1e6:.1f} us  {img.numel()*2/t/1e9:.0f} GB/s")
+
+
+def bench_qkv_fusion():
+    """A/B: qkv GEMM + separate QK-norm/RoPE kernel vs the fused epilogue (same process)."""
+    M, K, nh = 4352, 3072, 24
+    H = nh * 128
+    a, w, b = rnd(M, K), rnd(3 * H + 12288, K, scale=0.02), rnd(3 * H + 12288)
+    qkv = torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16)
+    cat = torch.empty(M, 12288, device=dev, dtype=torch.bfloat16)
+    table = torch.zeros(M, 64, 2, device=dev); table[..., 0] = 1
+    s128 = torch.ones(128, device=dev, dtype=torch.bfloat16)
+
+    def unfused():
+        ops.gemm([ops.Gemm(a, w, b, qkv, L.EPI_SPLIT_GELU, out2=cat, n_split=3 * H)])
+        ops.qknorm_rope(qkv, nh, [(M, s128, s128)], table)
+
+    def fused():
+        ops.gemm([ops.Gemm(a, w, b, qkv, L.EPI_QKV_NORM_ROPE, out2=cat, n_split=3 * H, norm_q=s128, norm_k=s128, rope=table)])
+    for _ in range(3):
+        tu, tf = timeit(unfused), timeit(fused)
+        print(f"linear1 (+norm/rope): unfused {tu*1e6:.1f} us, fused {tf*1e6:.1f} us", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "qkv":
+    bench_qkv_fusion()
