@@ -51,6 +51,12 @@ __device__ unsigned long long ca_attn_dbg[32];
 #if CA_ATTN_PRIO_MODE == 1
 #define CA_PRIO_HI() __builtin_amdgcn_s_setprio(1)
 #define CA_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#elif CA_ATTN_PRIO_MODE == 3  // matrix phase always outranks the partner's vector phase: g0 1/0, g1 2/1
+#define CA_PRIO_HI() if (grp) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1)
+#define CA_PRIO_LO() if (grp) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0)
+#elif CA_ATTN_PRIO_MODE == 4  // vector phase outranks the matrix phase
+#define CA_PRIO_HI() __builtin_amdgcn_s_setprio(0)
+#define CA_PRIO_LO() __builtin_amdgcn_s_setprio(2)
 #else
 #define CA_PRIO_HI()
 #define CA_PRIO_LO()
@@ -74,7 +80,8 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16 &s, int base) {
   return r;
 }
 
-__global__ __launch_bounds__(512, 2) void ca_attn_kernel(const AttnLaunch L) {
+template <int NW>  // waves per workgroup: 8 (256 query rows, 1 workgroup per CU) or 4 (128 rows, 2 per CU)
+__global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void ca_attn_kernel(const AttnLaunch L) {
 
   const int h = lane >> 5;    // lane half
   const int ql = lane & 31;   // query row within the wave / operand row
-  const int qrow0 = qb * 256 + wave * 32;
+  const int qrow0 = qb * (NW * 32) + wave * 32;
   const bool active = qrow0 < nq;  // wave-uniform
   const int qrow = min(qrow0 + ql, nq - 1);
 
@@ -108,34 +115,29 @@ __global__ __launch_bounds__(512, 2) void ca_attn_kernel(const AttnLaunch L) {
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8 *)(qp + ks * 16);
   }
 
-  // ---- staging geometry: thread moves pieces (tid) and (tid+512): key row r, 16-B chunk ch
-  const int st_r = tid >> 4, st_ch = tid & 15;
-  const int st_koff = st_r * 256 + ((st_ch ^ (st_r & 15)) << 4);
-  const int st_voff = st_r * 256 + ((st_ch ^ (((st_r & 3) << 2) | ((st_r >> 2) & 3))) << 4);
-  const bf16 *k0p = (const bf16 *)P.k0 + head * 128 + st_ch * 8;
-  const bf16 *v0p = (const bf16 *)P.v0 + head * 128 + st_ch * 8;
-  const bf16 *k1p = (const bf16 *)P.k1 + head * 128 + st_ch * 8;
-  const bf16 *v1p = (const bf16 *)P.v1 + head * 128 + st_ch * 8;
-
-  uint4 kreg0, kreg1, vreg0, vreg1;  // named (not arrays): keeps them in VGPRs
-#define CA_ATTN_LOAD_ROW(I, KR, VR)                                      \
-  {                                                                      \
-    const int kk = min(tile * KV_TILE + st_r + 32 * (I), nkeys - 1);     \
-    const bool s0 = kk < n0;                                             \
-    const size_t ro = (size_t)(s0 ? kk : kk - n0) * ldkv;                \
-    KR = *(const uint4 *)((s0 ? k0p : k1p) + ro);                        \
-    VR = *(const uint4 *)((s0 ? v0p : v1p) + ro);                        \
-  }
-  auto issue_loads = [&](int tile) {
-    CA_ATTN_LOAD_ROW(0, kreg0, vreg0)
-    CA_ATTN_LOAD_ROW(1, kreg1, vreg1)
-  };
-  auto write_lds = [&](int buf) {
+  // ---- staging by LDS-DMA (global_load_lds_dwordx4 from inline asm: no VGPR round trip, and hipcc does
+  // not order the tile's ds_reads behind it).  A tile is 16 pieces of 1 KiB (4 key rows) per matrix; the
+  // LDS image is lane-linear, so the XOR swizzles go on the per-lane SOURCE chunk.  The DMA of tile t+1
+  // is issued at the top of iteration t (its buffer was last read before the previous barrier) and
+  // retired with vmcnt(0) just before the barrier that ends iteration t.
+  const int st_row = lane >> 4, st_cp = lane & 15;
+  const bf16 *k0p = (const bf16 *)P.k0 + head * 128;
+  const bf16 *v0p = (const bf16 *)P.v0 + head * 128;
+  const bf16 *k1p = (const bf16 *)P.k1 + head * 128;
+  const bf16 *v1p = (const bf16 *)P.v1 + head * 128;
+  auto stage_tile = [&](int tile, int buf) {
     char *kb = smem + buf * BUF_BYTES;
-    *(uint4 *)(kb + st_koff) = kreg0;
-    *(uint4 *)(kb + TILE_BYTES + st_voff) = vreg0;
-    *(uint4 *)(kb + st_koff + 8192) = kreg1;
-    *(uint4 *)(kb + TILE_BYTES + st_voff + 8192) = vreg1;
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j) {
+      const int q = wave * (16 / NW) + j;
+      const int r = 4 * q + st_row;
+      const int kk = min(tile * KV_TILE + r, nkeys - 1);
+      const bool s0 = kk < n0;
+      const size_t ro = (size_t)(s0 ? kk : kk - n0) * ldkv;
+      ca_glds16_asm((s0 ? k0p : k1p) + ro + ((st_cp ^ (r & 15)) << 3), kb + q * 1024);
+      ca_glds16_asm((s0 ? v0p : v1p) + ro + ((st_cp ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 3),
+                    kb + TILE_BYTES + q * 1024);
+    }
   };
 
   // ---- fragment read offsets
@@ -160,13 +162,15 @@ __global__ __launch_bounds__(512, 2) void ca_attn_kernel(const AttnLaunch L) {
   const float sl2 = L.scale_log2;
 
   const int nt = (nkeys + KV_TILE - 1) / KV_TILE;
-  issue_loads(0);
-  write_lds(0);
+  stage_tile(0, 0);
+  // vmcnt(0) through the builtin (0x0F70): it also tells hipcc's wait-count pass that the Q-fragment
+  // loads have landed, so it adds no vmcnt waits for them inside the loop (they would drain the DMA)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) issue_loads(t + 1);
+    if (t + 1 < nt) stage_tile(t + 1, cur ^ 1);
     if (active) {
       const char *kbuf = smem + cur * BUF_BYTES;
       const char *vbuf = kbuf + TILE_BYTES;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void ca_attn_kernel(const AttnLaunch L) {
         }
       }
     }
-    if (t + 1 < nt) write_lds(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed (this wave's pieces)
     __syncthreads();
     cur ^= 1;
   }
@@ -574,6 +578,15 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
     ca_set_error("ca_attn_fwd_bf16: n_problems=%d num_heads=%d", n_problems, num_heads);
     return CA_ERR_ARG;
   }
+  // Default: 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: 295 us for
+  // 4352x4352x24 heads on MI355X.  A/B aids (same numerics): CA_ATTN_WAVES=4 = two independent 128-row
+  // workgroups per CU (321 us), CA_ATTN_PP=1 = the two-group ping-pong schedule below (350 us).
+  // What bounds all three (tools/micro/coissue.hip, tools/stamp_attn.py): per 64-key tile a wave issues
+  // 32 MFMAs (1024 cycles) and ~180 vector instructions of softmax (~850 cycles), and a vector wave next
+  // to a saturated MFMA wave on the same SIMD runs at only ~47 % of its solo speed.
+  static const bool use_pp = getenv("CA_ATTN_PP") != nullptr;
+  static const int nw = (getenv("CA_ATTN_WAVES") && atoi(getenv("CA_ATTN_WAVES")) == 4) ? 4 : 8;
+  const int qrows = use_pp ? 256 : nw * 32;
   AttnLaunch L = {};
   L.num_heads = num_heads;
   L.scale_log2 = scale * 1.4426950408889634f;
@@ -604,7 +617,7 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
       L.p[i].k1 = p.k0;
       L.p[i].v1 = p.v0;
     }
-    L.nqb[i] = (p.nq + 255) / 256;
+    L.nqb[i] = (p.nq + qrows - 1) / qrows;
     total += 8 * hx * L.nqb[i];
   }
   if (n_problems == 1) {
@@ -614,16 +627,12 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   } else {
     L.blocks_p1 = 8 * hx * L.nqb[1];
   }
-  // Two structures, same tiles and numerics.  Measured on MI355X (tools/stamp_attn.py, profiles/): both
-  // run 4352x4352x24 heads in ~320 us; per K/V tile the 32 MFMAs of a wave take ~1600 cycles even with
-  // no LDS reads and no concurrent vector work (the chip does not sustain back-to-back 32x32x16 MFMAs on
-  // all 256 CUs), so the ping-pong schedule buys nothing here yet.  The simple kernel (plain
-  // __syncthreads, register staging) is the default; CA_ATTN_PP=1 selects the ping-pong kernel.
-  static const bool use_simple = getenv("CA_ATTN_PP") == nullptr;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void *)ca_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void *)ca_attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        ATTN_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)ca_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)ca_attn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_PP_LDS);
     if (e != hipSuccess) {
@@ -632,10 +641,12 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
     }
     attr_done = true;
   }
-  if (use_simple)
-    hipLaunchKernelGGL(ca_attn_kernel, dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
-  else
+  if (use_pp)
     hipLaunchKernelGGL(ca_attn_pp_kernel, dim3(total), dim3(512), ATTN_PP_LDS, (hipStream_t)stream, L);
+  else if (nw == 8)
+    hipLaunchKernelGGL(ca_attn_kernel<8>, dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
+  else
+    hipLaunchKernelGGL(ca_attn_kernel<4>, dim3(total), dim3(256), ATTN_LDS, (hipStream_t)stream, L);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ca_set_error("ca_attn_fwd_bf16: launch failed: %s", hipGetErrorString(e));
