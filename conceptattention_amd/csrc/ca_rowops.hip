@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void ca_qknorm_rope_kernel(bf16 *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// out[v,n] (+)= sum_k f(x[v,k]) W[n,k] + bias[n]; one wave per output row n, x staged in LDS (fp32)
+// out[v,n] (+)= sum_k f(x[v,k]) W[n,k] + bias[n]; x (after f) staged in LDS as fp32.  A wave streams
+// GEMV_ROWS weight rows at a time so each 8-element slice of the NV input vectors is read from LDS
+// once per GEMV_ROWS rows (with one row per pass and NV = 8 the kernel was LDS-bound at 1.1 TB/s).
+constexpr int GEMV_ROWS = 4;
 template <int NV>
 __global__ __launch_bounds__(256) void ca_gemv_kernel(const float *__restrict__ x, int ldx,
                                                       const bf16 *__restrict__ W, const bf16 *__restrict__ bias,
@@ -160,32 +163,48 @@ __global__ __launch_bounds__(256) void ca_gemv_kernel(const float *__restrict__ 
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
-    const bf16 *wr = W + (size_t)n * K;
-    float acc[NV];
+  for (int n0 = (blockIdx.x * 4 + wave) * GEMV_ROWS; n0 < N; n0 += gridDim.x * 4 * GEMV_ROWS) {
+    float acc[GEMV_ROWS][NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+    for (int r = 0; r < GEMV_ROWS; ++r)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[r][v] = 0.f;
+    const bf16 *wr[GEMV_ROWS];
+#pragma unroll
+    for (int r = 0; r < GEMV_ROWS; ++r) wr[r] = W + (size_t)min(n0 + r, N - 1) * K;
     for (int k = lane * 8; k < K; k += 512) {
-      const bf16x8 w8 = *(const bf16x8 *)(wr + k);
+      bf16x8 w8[GEMV_ROWS];
+#pragma unroll
+      for (int r = 0; r < GEMV_ROWS; ++r) w8[r] = *(const bf16x8 *)(wr[r] + k);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const f32x4 a = *(const f32x4 *)(xs + v * K + k), b = *(const f32x4 *)(xs + v * K + k + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[v] = fmaf((float)w8[j], a[j], acc[v]);
-          acc[v] = fmaf((float)w8[4 + j], b[j], acc[v]);
-        }
+        for (int r = 0; r < GEMV_ROWS; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[r][v] = fmaf((float)w8[r][j], a[j], acc[r][v]);
+            acc[r][v] = fmaf((float)w8[r][4 + j], b[j], acc[r][v]);
+          }
       }
     }
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = wave_sum(acc[v]);
-    if (lane == 0) {
-      const float b = bias ? (float)bias[n] : 0.f;
+    for (int r = 0; r < GEMV_ROWS; ++r)
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        float *o = out + (size_t)v * ldo + n;
-        const float r = acc[v] + b;
-        *o = accumulate ? (*o + r) : r;
+      for (int v = 0; v < NV; ++v) acc[r][v] = wave_sum(acc[r][v]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < GEMV_ROWS; ++r) {
+        const int n = n0 + r;
+        if (n < N) {
+          const float bv = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            float *o = out + (size_t)v * ldo + n;
+            const float res = acc[r][v] + bv;
+            *o = accumulate ? (*o + res) : res;
+          }
+        }
       }
     }
   }
@@ -357,7 +376,8 @@ extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void 
     ca_set_error("ca_gemv_bf16: bad arguments (nv=%d N=%d K=%d; need 1<=nv<=8, K%%8==0, K<=4096)", nv, N, K);
     return CA_ERR_ARG;
   }
-  const int grid = (N + 3) / 4 < 4096 ? (N + 3) / 4 : 4096;
+  const int rows_per_block = 4 * GEMV_ROWS;
+  const int grid = (N + rows_per_block - 1) / rows_per_block < 4096 ? (N + rows_per_block - 1) / rows_per_block : 4096;
   const size_t lds = (size_t)nv * K * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 #define CA_GEMV_LAUNCH(NV)                                                                                     \

@@ -306,7 +306,7 @@ class HipFluxDiT:
     def precompute_conditioning(self, timesteps, y, concept_vec, guidance=None):
         """Conditioning vectors and every block's adaLN modulation for ALL diffusion steps up front
         (they depend only on (t, guidance, y), never on the activations): the 6.4 GB of modulation
-        weights are streamed once per 4 steps instead of once per step.  Step i is then selected
+        weights are streamed once per 2 steps instead of once per step.  Step i is then selected
         with ``cond_slot=i`` in the model call.  Same arithmetic as the in-call path
         (modified_flux_dit.py:99-119, flux/modules/layers.py:113-126)."""
         p, W, dev = self.params, self.weights, self.device
@@ -328,8 +328,10 @@ class HipFluxDiT:
         if p.guidance_embed:
             gemb = torch.empty(2 * n, 256, **f32)
             ops.timestep_embedding(torch.full((2 * n,), float(guidance), **f32), gemb)
-        for r0 in range(0, 2 * n, 8):
-            r = slice(r0, min(r0 + 8, 2 * n))
+        # 4 vectors (= 2 steps) per pass: 4 x 3072 fp32 inputs leave room for 3 workgroups per CU in LDS;
+        # with 8 the weight stream drops from 5.3 to 2.2 TB/s (measured, tools/gemv_bench.py)
+        for r0 in range(0, 2 * n, 4):
+            r = slice(r0, min(r0 + 4, 2 * n))
             ops.gemv(temb[r], W["time_in.in_layer.weight"], W["time_in.in_layer.bias"], hv[r])
             ops.gemv(hv[r], W["time_in.out_layer.weight"], W["time_in.out_layer.bias"], vecs[r], silu_input=True)
             if p.guidance_embed:

@@ -88,10 +88,11 @@ if __name__ == "__main__" and len(sys.argv) == 1:
     t = timeit(lambda: ops.qknorm_rope(qkv, 24, [(4356, s128, s128)], table))
     print(f"qknorm_rope 4356x6144: {t*1e6:.1f} us  {2*4356*6144*2/t/1e9:.0f} GB/s")
     w = rnd(18432 * 8, 3072, scale=0.02)
-    xv = torch.randn(2, 3072, device=dev)
-    ov = torch.empty(2, 18432 * 8, device=dev)
-    t = timeit(lambda: ops.gemv(xv, w, None, ov, silu_input=True))
-    print(f"gemv 2x3072 -> {w.shape[0]}: {t*1e6:.1f} us  {w.numel()*2/t/1e9:.0f} GB/s")
+    for nv in (2, 8):
+        xv = torch.randn(nv, 3072, device=dev)
+        ov = torch.empty(nv, 18432 * 8, device=dev)
+        t = timeit(lambda: ops.gemv(xv, w, None, ov, silu_input=True))
+        print(f"gemv {nv}x3072 -> {w.shape[0]}: {t*1e6:.1f} us  {w.numel()*2/t/1e9:.0f} GB/s")
     img, con = rnd(4096, 3072), rnd(4, 3072)
     lg = torch.empty(4, 4096, device=dev)
     acc = torch.zeros(4, 4096, device=dev)
