@@ -114,7 +114,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
-    dev = torch.device(f"cuda:{local}")
+    # CA_BENCH_DEVICE pins every rank to one device (multi-process rehearsal on a 1-GPU box, with
+    # CA_DIST_BACKEND=gloo since RCCL refuses two ranks on one GPU); normally rank r uses GPU LOCAL_RANK
+    dev = torch.device(os.environ.get("CA_BENCH_DEVICE") or f"cuda:{local}")
     torch.cuda.set_device(dev)
     if L.load().ca_check_device() != 0:
         raise SystemExit(L.load().ca_last_error().decode())

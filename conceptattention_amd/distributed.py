@@ -28,7 +28,7 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -51,15 +51,17 @@ def gather_heatmaps(local_maps: torch.Tensor, n_items: int, rank: int, world: in
     if world == 1:
         return local_maps
     per = (n_items + world - 1) // world
-    pad = torch.zeros((per,) + tuple(local_maps.shape[1:]), dtype=local_maps.dtype, device=local_maps.device)
+    # RCCL works on the device tensors directly; gloo (CPU rehearsals) goes through host memory
+    dev = local_maps.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    pad = torch.zeros((per,) + tuple(local_maps.shape[1:]), dtype=local_maps.dtype, device=dev)
     pad[: len(mine)] = local_maps
-    out = torch.empty((world, per) + tuple(local_maps.shape[1:]), dtype=local_maps.dtype, device=local_maps.device)
+    out = torch.empty((world, per) + tuple(local_maps.shape[1:]), dtype=local_maps.dtype, device=dev)
     dist.all_gather_into_tensor(out.view(world * per, *local_maps.shape[1:]), pad)
-    full = torch.empty((n_items,) + tuple(local_maps.shape[1:]), dtype=local_maps.dtype, device=local_maps.device)
+    full = torch.empty((n_items,) + tuple(local_maps.shape[1:]), dtype=local_maps.dtype, device=dev)
     for r in range(world):
         idx = shard_items(n_items, r, world)
         full[idx] = out[r, : len(idx)]
-    return full
+    return full.to(local_maps.device)
 
 
 def allreduce_sum_(acc: torch.Tensor) -> torch.Tensor:
@@ -71,9 +73,10 @@ def allreduce_sum_(acc: torch.Tensor) -> torch.Tensor:
 
 
 def max_over_ranks(value: float, device) -> float:
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
