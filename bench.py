@@ -185,6 +185,41 @@ def main():
     elapsed = D.max_over_ranks(elapsed, dev)
 
     calls = n_timed
+
+    # ---- the "concept-attention block" figure of BASELINE.json: average duration of a double block
+    # (HIP events around each of the 19 block calls of one extra, untimed forward; rank 0 only)
+    block = None
+    if rank == 0:
+        m = pipe.model
+        i0 = inputs[timed_items[0]]
+        from conceptattention_amd import sampling as S_
+        con, con_ids, con_vec = S_.concept_inputs(i0["concepts"], i0["vec"])
+        inp0 = S_.prepare_from_embeddings(i0["latent"].to(dev, torch.bfloat16), i0["txt"], i0["vec"])
+        evs = []
+        orig = m._double_block
+
+        def timed_block(*a, **k):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            orig(*a, **k)
+            e_.record()
+            evs.append((s_, e_))
+        m._double_block = timed_block
+        try:
+            m(img=inp0["img"], img_ids=inp0["img_ids"], txt=inp0["txt"], txt_ids=inp0["txt_ids"], concepts=con,
+              concept_ids=con_ids, concept_vec=con_vec, y=inp0["vec"], timesteps=torch.full((1,), 1.0, device=dev),
+              guidance=torch.zeros(1, device=dev), stop_after_multimodal_attentions=True, return_vectors=False)
+        finally:
+            m._double_block = orig
+        torch.cuda.synchronize()
+        us = sorted(s_.elapsed_time(e_) * 1e3 for s_, e_ in evs)
+        med = us[len(us) // 2]
+        H_, MLP_, NH_, D_ = p.hidden_size, p.mlp_hidden, p.num_heads, p.head_dim
+        dbl_flops = ((2 * H_ * 3 * H_ + 2 * H_ * H_ + 4 * H_ * MLP_) * (Lp + T + C) + 4 * (Lp + T) ** 2 * D_ * NH_
+                     + 4 * C * (C + Lp) * D_ * NH_ + 3 * 2 * H_ * 6 * H_)
+        block = {"what": "ModifiedDoubleStreamBlock-equivalent (7 launches), median of 19", "us": med,
+                 "tflop": dbl_flops / 1e12, "achieved_tflops": dbl_flops / med / 1e6,
+                 "mfma_frac": dbl_flops / med / 1e6 / MFMA_BF16_PEAK_TFLOPS}
     maps_ok = bool(torch.isfinite(all_maps).all().item()) and abs(all_maps[:, 0].sum(1).mean().item() - 1.0) < 1e-3
 
     if rank == 0:
@@ -242,6 +277,7 @@ def main():
             "calls_per_s": calls / elapsed,
             "outputs_finite_and_normalised": maps_ok,
             "roofline": roof,
+            "concept_attention_block": block,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, Lp, T, C, args.diffusion_steps, p.depth, p.depth_single_blocks)
