@@ -273,9 +273,12 @@ class ConceptAttentionFluxPipeline:
                      layer_indices=list(range(15, 19)), num_samples: int = 1, num_steps: int = 4,
                      noise_timestep: int = 2, device: str = "cuda:0", return_pil_heatmaps: bool = True,
                      seed: int = 0, cmap="plasma", stop_after_multi_modal_attentions=True,
-                     attention_norm: str = "sparsemax", softmax=True) -> ConceptAttentionPipelineOutput:
+                     attention_norm: str = "sparsemax", softmax=True,
+                     joint_attention_kwargs=None) -> ConceptAttentionPipelineOutput:
         """``image``: a latent tensor (1,16,h/8,w/8), or a PIL image when an autoencoder was injected.
-        One forward of the 19 double blocks per noise sample (stop_after_multimodal_attentions)."""
+        One forward of the 19 double blocks per noise sample (stop_after_multimodal_attentions).
+        ``joint_attention_kwargs`` (not in the reference's signature, which hard-codes None at :296) lets the
+        segmentation harness select the concept cross/self-attention ablations."""
         assert all([0 <= li < self.params.depth for li in layer_indices]), "Invalid layer index"
         assert height == width, "Height and width must be the same for now"
         if not (softmax or attention_norm == "softmax"):
@@ -309,7 +312,7 @@ class ConceptAttentionFluxPipeline:
                        concepts=con, concept_ids=con_ids, concept_vec=con_vec, y=con_vec, timesteps=t_vec,
                        guidance=torch.zeros(1, device=self.device),
                        stop_after_multimodal_attentions=stop_after_multi_modal_attentions,
-                       joint_attention_kwargs=None, return_vectors=False, heatmaps=req)
+                       joint_attention_kwargs=joint_attention_kwargs, return_vectors=False, heatmaps=req)
         side = int(round(n_patches ** 0.5))
         return self._finish(image, req.out_space.view(1, C, side, side), req.cross_space.view(1, C, side, side),
                             return_pil_heatmaps, cmap)

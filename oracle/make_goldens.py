@@ -17,6 +17,7 @@ Fixtures
   block_full_dev.npz                ONE full-size double block at the flux-dev token counts (T=512, C=8)
   heatmap_kat.npz                   compute_heatmaps_from_vectors known answers (softmax branch)
   sampler.npz                       get_schedule / prepare-patchify / unpack / denoise (tiny, 2 steps)
+  metrics.npz                       segmentation scores of concept_attention/utils.py on seeded masks / maps
 """
 from __future__ import annotations
 
@@ -303,12 +304,43 @@ def sampler(ref, out_dir):
     print("sampler done", arrays["schedule_schnell_4"])
 
 
+def metrics(ref, out_dir):
+    """pixel accuracy / IoU areas / AP of the reference's utils on seeded 2-class cases, driven the way
+    experiments/imagenet_segmentation/run_experiment.py:205-219 drives them."""
+    from concept_attention import utils as U
+    g = torch.Generator().manual_seed(21)
+    arrays = {}
+    for i, (h, w) in enumerate([(224, 224), (64, 64), (17, 9)]):
+        label = (torch.rand(h, w, generator=g) > 0.6).float()
+        coeff = (0.6 * label + 0.8 * torch.rand(h, w, generator=g)).clamp(0, 1)
+        coeff = (coeff * 16).round() / 16            # many tied scores: exercises the threshold grouping of AP
+        mask = (coeff > coeff.mean()).float()
+        m2, y2 = torch.stack((1 - mask, mask)), torch.stack((1 - label, label))
+        cor, lab = U.batch_pix_accuracy(m2, y2)
+        inter, union = U.batch_intersection_union(m2, y2, nclass=2)
+        ap = U.get_ap_scores(torch.stack((1 - coeff, coeff)).unsqueeze(0), label.unsqueeze(0))
+        arrays.update({f"label{i}": label.numpy().astype(np.uint8), f"coeff{i}": coeff.numpy(),
+                       f"mask{i}": mask.numpy().astype(np.uint8), f"pix{i}": np.array([cor, lab]),
+                       f"inter{i}": inter, f"union{i}": union, f"ap{i}": np.array(ap)})
+    # multi-class label map with an ignored (-1) region, for get_ap_scores' ignore_index handling
+    tgt = torch.randint(-1, 3, (12, 10), generator=g)
+    pred = torch.rand(3, 12, 10, generator=g)
+    arrays["mc_target"] = tgt.numpy()
+    arrays["mc_pred"] = pred.numpy()
+    arrays["mc_ap"] = np.array(U.get_ap_scores(pred.unsqueeze(0), tgt.unsqueeze(0)))
+    x = torch.randn(3, 5, 7, generator=g)
+    arrays["linnorm_in"] = x.numpy()
+    arrays["linnorm_out"] = U.linear_normalization(x, dim=-2).numpy()
+    np.savez_compressed(os.path.join(out_dir, "metrics.npz"), **arrays)
+    print("metrics", arrays["pix0"], arrays["ap0"], arrays["mc_ap"])
+
+
 def main():
     torch.set_num_threads(8)
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     ref = _import_reference()
-    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "full", "fulldev"]
+    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "metrics", "full", "fulldev"]
     if "tiny" in which:
         tiny_model(ref, out_dir, False, "tiny_schnell.npz")
         tiny_model(ref, out_dir, True, "tiny_dev.npz")
@@ -318,6 +350,8 @@ def main():
         heatmap_kat(ref, out_dir)
     if "sampler" in which:
         sampler(ref, out_dir)
+    if "metrics" in which:
+        metrics(ref, out_dir)
     if "full" in which:
         full_blocks(ref, out_dir)
     if "fulldev" in which:

@@ -153,3 +153,31 @@ def test_heatmap_known_answers_through_hip(golden):
     outn = compute_heatmaps_from_vectors(iv.to(DEV), cv.to(DEV), layer_indices=[2], timesteps=[1],
                                          normalize_concepts=True)
     assert (outn.cpu() - refn).abs().max() < 5e-3  # normalised concepts are re-rounded to bf16
+
+
+def test_segmentation_model_contract(pipe):
+    """The segmentation wrapper (concept_attention/segmentation.py:34-81): target-concept masks are the
+    mean-thresholded heat map of encode_image; the ablation kwargs reach the blocks."""
+    from conceptattention_amd.segmentation import ConceptAttentionSegmentationModel, SegmentationScores, \
+        prepare_for_scoring
+    seg = ConceptAttentionSegmentationModel(pipe)
+    latent = torch.randn(1, 16, 32, 32, generator=torch.Generator().manual_seed(0))
+    concepts = ["dragon", "rock", "sky"]
+    kw = dict(width=256, height=256, layers=[0, 1], num_samples=1, seed=3)
+    masks, coeffs, recon = seg([latent, latent], target_concepts=["rock", "dragon"], concepts=concepts,
+                               captions=["a rock", "a dragon"], **kw)
+    assert len(masks) == 2 and masks[0].shape == (16, 16) and masks[0].dtype == np.bool_ and recon == [None, None]
+    ref = pipe.encode_image(latent, concepts, prompt="a rock", width=256, height=256, layer_indices=[0, 1],
+                            seed=3, return_pil_heatmaps=False).concept_heatmaps
+    assert np.array_equal(coeffs[0], np.asarray(ref)[1])
+    assert np.array_equal(masks[0], coeffs[0] > coeffs[0].mean())
+    all_masks, all_coeffs, _ = seg(latent, target_concepts=None, concepts=concepts, captions=["a rock"], **kw)
+    assert all_masks[0].shape == (3, 16, 16) and all_masks[0].dtype == torch.bool
+    _, abl, _ = seg(latent, target_concepts=["rock"], concepts=concepts, captions=["a rock"],
+                    joint_attention_kwargs={"concept_cross_attention": True, "concept_self_attention": False}, **kw)
+    assert not np.array_equal(abl[0], coeffs[0])
+    sc = SegmentationScores()
+    c, m = prepare_for_scoring(coeffs[0], masks[0], size=32)
+    sc.update(m, c, m.bool().numpy())                   # scoring a mask against itself is perfect
+    r = sc.result()
+    assert r["pixAcc"] == pytest.approx(1.0) and r["mIoU"] == pytest.approx(1.0) and r["mAP"] == pytest.approx(1.0)
