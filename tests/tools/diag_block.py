@@ -1,6 +1,6 @@
 """Stage-by-stage error of the HIP double block vs the fp32 oracle (full size)."""
 import math, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from conceptattention_amd import ops
@@ -72,7 +72,7 @@ w = torch.softmax(qq @ kk.transpose(1, 2) / math.sqrt(128), -1)
 st("ATT con (hip q,k,v inputs)", m.ATT[:C], (w @ vv).transpose(0, 1).reshape(C, H))
 # logits from mixed sources
 import numpy as np
-g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "block_full.npz"))
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "golden", "block_full.npz"))
 ref_lo = torch.from_numpy(g["logits_output_space"][0])
 lo = torch.empty(C, L, device=DEV)
 ops.heatmap_logits(m.ATT[CT:], m.ATT[:C], lo)

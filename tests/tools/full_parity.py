@@ -3,7 +3,7 @@ step (19 double + 38 single blocks) on the HIP path vs the fp32 CPU oracle with 
 weights, NOT teacher-forced, so it shows how the bf16 error grows with depth.  Writes
 gpurun_out/full_parity.json (copied to profiles/).  Takes ~10 min of host CPU for the oracle."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from conceptattention_amd.flux_dit import HipFluxDiT, HeatmapRequest, DICT_KEYS
