@@ -51,14 +51,18 @@ __device__ __forceinline__ uint32_t ca_pack2(float lo, float hi) {
 }
 
 __device__ __forceinline__ float ca_gelu_tanh(float x) {
-  // nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  const float e = __expf(2.0f * u);
-  const float t = 1.0f - 2.0f / (e + 1.0f);  // tanh(u); e=inf -> 1, e=0 -> -1
-  return 0.5f * x * (1.0f + t);
+  // nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  With
+  // 0.5 (1 + tanh(u)) = sigmoid(2u) this is x / (1 + exp(-2u)); exp(-2u) = exp2(x (k0 + k1 x^2)),
+  // k0 = -2 sqrt(2/pi) log2(e), k1 = 0.044715 k0: 3 mul/fma + v_exp_f32 + add + v_rcp_f32 + mul
+  // (an IEEE divide alone is ~10 instructions).  x -> -inf: exp2 -> inf, rcp -> 0; x -> +inf: exp2 -> 0.
+  const float p = __builtin_fmaf(x * x, -0.10294323f, -2.3022082f);
+  const float e = __builtin_amdgcn_exp2f(x * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-__device__ __forceinline__ float ca_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float ca_silu(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950409f * x));
+}
 
 // host-side error plumbing (ca_api.cpp)
 void ca_set_error(const char *fmt, ...);

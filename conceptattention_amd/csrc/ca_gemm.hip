@@ -259,6 +259,22 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_kernel(const GemmLaunch L) {
 // own group and, one barrier later, in the other group.  Restaging a buffer happens >= 3 phases
 // after its last ds_read.  K tiles past the end are staged from the clamped last tile into a
 // buffer nobody reads again, so the wait counts stay uniform without a loop tail.
+#ifdef CA_GEMM_STAMP
+// Diagnostic build only (tools/stamp_gemm.py): s_memtime of wave 0 of every workgroup at kernel entry, after the
+// prologue barrier, after the K loop and after the epilogue.
+__device__ unsigned long long ca_gemm_dbg[4 * 2048];
+#define CA_GSTAMP(SLOT)                                                                 \
+  {                                                                                     \
+    unsigned long long ts_;                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    if (tid == 0 && blockIdx.x < 2048) ca_gemm_dbg[blockIdx.x * 4 + (SLOT)] = ts_;      \
+  }
+#else
+#define CA_GSTAMP(SLOT)
+#endif
+
 template <int NL, int NHI>  // 16-column fragments per wave in the lo / hi half of the W tile
 struct PPCfg {
   static constexpr int BM = 256, BN = 64 * (NL + NHI), BK = 64, ROW_BYTES = 128;
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  CA_GSTAMP(0);
 
   const int nblk = gridDim.x;
   const int bid = blockIdx.x;
@@ -417,6 +434,7 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
   stageWL(1, 1);
   ca_wait_vmcnt<C::CNT_A + NL>();
   CA_PP_SYNC();
+  CA_GSTAMP(1);
   if (wm == 1) { CA_PP_SYNC(); }  // stagger: group 1 runs one barrier behind group 0
 
   // retire-waits leave the two youngest half tiles in flight: phase 1: WL(t+2 of the previous
@@ -457,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
   }
   if (wm == 0) { CA_PP_SYNC(); }
   ca_wait_vmcnt<0>();  // no LDS-DMA may be outstanding when the workgroup retires
+  CA_GSTAMP(2);
 
   // ---- epilogue.  acc[mi][nj][r] = C[m][n]:
   //   m = m0 + (mi>>2)*128 + wm*64 + 16*(mi&3) + (lane&15)
@@ -578,18 +597,23 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
         }
       }
     }
+    // the residual rows are fetched up front for all 8 row fragments (rows clamped, only the store is
+    // predicated): one round trip to memory instead of eight dependent ones
+    uint2 res[8][NF];
+    if (epi == CA_EPI_GATE_RESIDUAL) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1);
+        const uint2 *rp = (const uint2 *)((const char *)P.resid + ((size_t)m * P.ldr + nb) * 2);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) res[mi][j] = rp[j];
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
       const int m = m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
-      if (m >= M) continue;
       uint2 *op = (uint2 *)(outb + ((size_t)m * ldo + nb + col_shift) * 2);
-      uint2 res[NF];
       const bool first = m < P.gate_rows;
-      if (epi == CA_EPI_GATE_RESIDUAL) {
-        const uint2 *rp = (const uint2 *)((const char *)P.resid + ((size_t)m * P.ldr + nb) * 2);
-#pragma unroll
-        for (int j = 0; j < NF; ++j) res[j] = rp[j];
-      }
       uint2 o[NF];
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
@@ -600,21 +624,27 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
           if (epi == CA_EPI_GELU_TANH) v[r] = ca_gelu_tanh(v[r]);
         }
         if (epi == CA_EPI_GATE_RESIDUAL) {
-          const bf16x4 r4 = __builtin_bit_cast(bf16x4, res[j]);
+          const bf16x4 r4 = __builtin_bit_cast(bf16x4, res[mi][j]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = (float)r4[r] + (first ? gate_a[4 * j + r] : gate_b[4 * j + r]) * v[r];
         }
         o[j] = make_uint2(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]));
       }
-      if constexpr (NF == 2) {
-        *(uint4 *)op = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
-      } else {
-        op[0] = o[0];
+      if (m < M) {
+        if constexpr (NF == 2) {
+          *(uint4 *)op = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+        } else {
+          op[0] = o[0];
+        }
       }
     }
   };
   half_epilogue(std::integral_constant<int, NL>{}, 0, n0 + wn * 16 * NL + 4 * NL * g);
   half_epilogue(std::integral_constant<int, NHI>{}, NL, n0 + 64 * NL + wn * 16 * NHI + 4 * NHI * g);
+#ifdef CA_GEMM_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CA_GSTAMP(3);
+#endif
 }
 
 template <int NL, int NHI>
@@ -818,3 +848,9 @@ extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems,
     default: return launch<8, 1>(L, total, s);
   }
 }
+
+#ifdef CA_GEMM_STAMP
+extern "C" int ca_debug_read_gemm(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_gemm_dbg), sizeof(unsigned long long) * 4 * 2048);
+}
+#endif
