@@ -23,6 +23,7 @@ class GemmProblem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
                 ("resid", C.c_void_p), ("gate", C.c_void_p), ("gate2", C.c_void_p), ("out2", C.c_void_p),
                 ("norm_q", C.c_void_p), ("norm_k", C.c_void_p), ("rope", C.c_void_p), ("q_prerope", C.c_void_p),
+                ("a_scale", C.c_void_p), ("w_scale", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("ld2", C.c_int32), ("n_split", C.c_int32), ("gate_rows", C.c_int32),
@@ -51,9 +52,14 @@ SIGNATURES = {
     "ca_check_device": (C.c_int, []),
     "ca_gemm_bf16": (C.c_int, [C.POINTER(GemmProblem), C.c_int32, C.c_int32, C.c_void_p]),
     "ca_gemm_auto_tile": (C.c_int, [C.POINTER(GemmProblem), C.c_int32]),
+    "ca_gemm_fp8": (C.c_int, [C.POINTER(GemmProblem), C.c_int32, C.c_void_p]),
     "ca_attn_fwd_bf16": (C.c_int, [C.POINTER(AttnProblem), C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "ca_ln_modulate_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),
+    "ca_ln_modulate_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),
+    "ca_quantize_rows_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_void_p]),
     "ca_qknorm_rope_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(NormSegment),
                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ca_gemv_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

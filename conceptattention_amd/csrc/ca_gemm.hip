@@ -259,6 +259,14 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_kernel(const GemmLaunch L) {
 // own group and, one barrier later, in the other group.  Restaging a buffer happens >= 3 phases
 // after its last ds_read.  K tiles past the end are staged from the clamped last tile into a
 // buffer nobody reads again, so the wait counts stay uniform without a loop tail.
+typedef int ca_v4i __attribute__((ext_vector_type(4)));
+typedef int ca_v8i __attribute__((ext_vector_type(8)));
+// two 16-byte LDS chunks -> the 32-byte fp8 operand of the K=128 MFMA
+__device__ __forceinline__ ca_v8i ca_cat32(bf16x8 lo, bf16x8 hi) {
+  const ca_v4i a = __builtin_bit_cast(ca_v4i, lo), b = __builtin_bit_cast(ca_v4i, hi);
+  return ca_v8i{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
 #ifdef CA_GEMM_STAMP
 // Diagnostic build only (tools/stamp_gemm.py): s_memtime of wave 0 of every workgroup at kernel entry, after the
 // prologue barrier, after the K loop and after the epilogue.
@@ -299,10 +307,17 @@ __device__ __forceinline__ void ca_wait_vmcnt() {
   if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 }
 
-template <int NL, int NHI>
+// FP8: A and W hold OCP e4m3 bytes; a 128-byte LDS row is then 128 k-elements and the two 16-byte chunks a
+// lane reads per fragment form the 32-byte operand of ONE v_mfma_scale_f32_16x16x128_f8f6f4 (E8M0 scales fixed
+// at 2^0; the lane->k assignment is the same for both operands, which is all an unscaled product needs:
+// tools/micro/mfma_fp8_probe.hip).  Same staging, barriers and wait counts; half the MFMA instructions, each
+// twice as long, so a K tile costs the same cycles and carries twice the FLOPs.  Row scales of A and W
+// (per-token / per-output-channel absmax quantisation) multiply the accumulators before the epilogue.
+template <int NL, int NHI, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) {
   using C = PPCfg<NL, NHI>;
   constexpr int NT_ = NL + NHI;
+  constexpr uint32_t ES = FP8 ? 1u : 2u;  // bytes per operand element
   extern __shared__ __attribute__((aligned(128))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
   const int M = P.M;
   const char *Ab = (const char *)P.A;
   const char *Wb = (const char *)P.W;
-  const int nk = P.K / C::BK;
+  const int nk = (int)((uint32_t)P.K * ES / C::ROW_BYTES);
 
   // ---- per-lane source offsets (bytes, k = 0) of the staging loads of each half tile
   uint32_t offA[2][C::CNT_A], offWL[NL], offWH[NHI];
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
       const int rr = i * 64 + wave * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((rr >> 1) & 7);
       const int row = min(m0 + h * 128 + rr, M - 1);
-      offA[h][i] = ((uint32_t)row * (uint32_t)P.lda + (uint32_t)c * 8u) * 2u;
+      offA[h][i] = (uint32_t)row * (uint32_t)P.lda * ES + (uint32_t)c * 16u;
     }
   auto w_src = [&](int rr, int nfrag, int nbase) {
     // LDS row rr of a W half holds weight row nbase + perm(rr): within each wave's 16*nfrag rows the
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
     const int wloc = rr % (16 * nfrag);
     const int j = wloc >> 4, a = (wloc >> 2) & 3, b = wloc & 3;
     const int n = nbase + (rr - wloc) + 4 * nfrag * a + 4 * j + b;
-    return ((uint32_t)n * (uint32_t)P.ldw + (uint32_t)c * 8u) * 2u;
+    return (uint32_t)n * (uint32_t)P.ldw * ES + (uint32_t)c * 16u;
   };
 #pragma unroll
   for (int i = 0; i < NL; ++i) offWL[i] = w_src(i * 64 + wave * 8 + (lane >> 3), NL, n0);
@@ -412,9 +427,17 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
 #define CA_PP_MMA(MI0, NJ0, WF, NW)                                                                         \
   {                                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                          \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)       \
-        _Pragma("unroll") for (int nj = 0; nj < (NW); ++nj) acc[(MI0) + mi][(NJ0) + nj] =                   \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nj][ks], af[mi][ks], acc[(MI0) + mi][(NJ0) + nj], 0, 0, 0); \
+    if constexpr (FP8) {                                                                                    \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int nj = 0; nj < (NW); ++nj)  \
+          acc[(MI0) + mi][(NJ0) + nj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                   \
+              ca_cat32(WF[nj][0], WF[nj][1]), ca_cat32(af[mi][0], af[mi][1]), acc[(MI0) + mi][(NJ0) + nj],  \
+              0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                                                          \
+    } else {                                                                                                \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)     \
+          _Pragma("unroll") for (int nj = 0; nj < (NW); ++nj) acc[(MI0) + mi][(NJ0) + nj] =                 \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nj][ks], af[mi][ks], acc[(MI0) + mi][(NJ0) + nj],  \
+                                                      0, 0, 0);                                             \
+    }                                                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                                          \
   }
 #define CA_PP_SYNC()                        \
@@ -476,6 +499,23 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
   if (wm == 0) { CA_PP_SYNC(); }
   ca_wait_vmcnt<0>();  // no LDS-DMA may be outstanding when the workgroup retires
   CA_GSTAMP(2);
+  if constexpr (FP8) {
+    // dequantise: acc[m][n] *= a_scale[m] * w_scale[n] (column order of the accumulators: see below)
+    float sa[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+      sa[mi] = P.a_scale[min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1)];
+#pragma unroll
+    for (int nj = 0; nj < NT_; ++nj) {
+      const int n = nj < NL ? n0 + wn * 16 * NL + 4 * NL * (lane >> 4) + 4 * nj
+                            : n0 + 64 * NL + wn * 16 * NHI + 4 * NHI * (lane >> 4) + 4 * (nj - NL);
+      const f32x4 sw = *(const f32x4 *)(P.w_scale + n);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][nj][r] *= sa[mi] * sw[r];
+    }
+  }
 
   // ---- epilogue.  acc[mi][nj][r] = C[m][n]:
   //   m = m0 + (mi>>2)*128 + wm*64 + 16*(mi&3) + (lane&15)
@@ -647,12 +687,12 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
 #endif
 }
 
-template <int NL, int NHI>
+template <int NL, int NHI, bool FP8 = false>
 int launch_pp(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
   using C = PPCfg<NL, NHI>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_pp_kernel<NL, NHI>,
+    hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_pp_kernel<NL, NHI, FP8>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
       ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
@@ -660,7 +700,7 @@ int launch_pp(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((ca_gemm_pp_kernel<NL, NHI>), dim3(total_tiles), dim3(512), C::LDS_BYTES, stream, L);
+  hipLaunchKernelGGL((ca_gemm_pp_kernel<NL, NHI, FP8>), dim3(total_tiles), dim3(512), C::LDS_BYTES, stream, L);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ca_set_error("ca_gemm_bf16: launch failed: %s", hipGetErrorString(e));
@@ -755,16 +795,27 @@ extern "C" int ca_gemm_auto_tile(const ca_gemm_problem *problems, int32_t n_prob
   return t;
 }
 
-extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
-                            ca_stream_t stream) {
+namespace {
+
+// shared argument checking + launch of ca_gemm_bf16 / ca_gemm_fp8 (FN = the entry point's name for messages)
+int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile, ca_stream_t stream, bool fp8,
+              const char *FN) {
   if (!problems || n_problems < 1 || n_problems > CA_GEMM_MAX_PROBLEMS) {
-    ca_set_error("ca_gemm_bf16: n_problems=%d out of range [1,%d]", n_problems, CA_GEMM_MAX_PROBLEMS);
+    ca_set_error("%s: n_problems=%d out of range [1,%d]", FN, n_problems, CA_GEMM_MAX_PROBLEMS);
     return CA_ERR_ARG;
+  }
+  if (fp8) {
+    if (tile != CA_TILE_AUTO && tile != CA_TILE_PP_256x256) {
+      ca_set_error("%s: only the 256x256 ping-pong tile has an fp8 variant (tile=%d)", FN, tile);
+      return CA_ERR_ARG;
+    }
+    tile = CA_TILE_PP_256x256;
   }
   if (tile == CA_TILE_AUTO) tile = auto_tile(problems, n_problems);
   const int bn = tile_n_of(tile);
+  const int kq = fp8 ? 128 : 64, ldq = fp8 ? 16 : 8, es = fp8 ? 1 : 2;
   if (!bn) {
-    ca_set_error("ca_gemm_bf16: no tile configuration fits (tile=%d)", tile);
+    ca_set_error("%s: no tile configuration fits (tile=%d)", FN, tile);
     return CA_ERR_ARG;
   }
   GemmLaunch L = {};
@@ -772,35 +823,39 @@ extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems,
   for (int i = 0; i < n_problems; ++i) {
     const ca_gemm_problem &p = problems[i];
     if (!p.A || !p.W || !p.out || p.M < 1 || p.N < 1 || p.K < 64) {
-      ca_set_error("ca_gemm_bf16[%d]: null pointer or empty shape (M=%d N=%d K=%d)", i, p.M, p.N, p.K);
+      ca_set_error("%s[%d]: null pointer or empty shape (M=%d N=%d K=%d)", FN, i, p.M, p.N, p.K);
       return CA_ERR_ARG;
     }
-    if (p.K % 64 || p.N % bn || p.lda % 8 || p.ldw % 8 || p.ldc % 8) {
-      ca_set_error("ca_gemm_bf16[%d]: need K%%64==0, N%%%d==0, ld%%8==0 (M=%d N=%d K=%d lda=%d ldw=%d ldc=%d)", i,
-                   bn, p.M, p.N, p.K, p.lda, p.ldw, p.ldc);
+    if (p.K % kq || p.N % bn || p.lda % ldq || p.ldw % ldq || p.ldc % 8) {
+      ca_set_error("%s[%d]: need K%%%d==0, N%%%d==0, lda/ldw%%%d==0, ldc%%8==0 (M=%d N=%d K=%d lda=%d ldw=%d ldc=%d)",
+                   FN, i, kq, bn, ldq, p.M, p.N, p.K, p.lda, p.ldw, p.ldc);
+      return CA_ERR_ARG;
+    }
+    if (fp8 && (!p.a_scale || !p.w_scale || ((uintptr_t)p.w_scale & 15) || ((uintptr_t)p.a_scale & 3))) {
+      ca_set_error("%s[%d]: fp8 operands need a_scale (fp32 [M]) and w_scale (fp32 [N], 16-byte aligned)", FN, i);
       return CA_ERR_ARG;
     }
     if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out | (uintptr_t)p.bias) & 15) {
-      ca_set_error("ca_gemm_bf16[%d]: pointers must be 16-byte aligned", i);
+      ca_set_error("%s[%d]: pointers must be 16-byte aligned", FN, i);
       return CA_ERR_ARG;
     }
     if (p.lda < p.K || p.ldw < p.K) {
-      ca_set_error("ca_gemm_bf16[%d]: lda/ldw smaller than K", i);
+      ca_set_error("%s[%d]: lda/ldw smaller than K", FN, i);
       return CA_ERR_ARG;
     }
-    if ((uint64_t)p.M * p.lda * 2 >= (1ull << 32) || (uint64_t)p.N * p.ldw * 2 >= (1ull << 32)) {
-      ca_set_error("ca_gemm_bf16[%d]: operand larger than 4 GiB", i);
+    if ((uint64_t)p.M * p.lda * es >= (1ull << 32) || (uint64_t)p.N * p.ldw * es >= (1ull << 32)) {
+      ca_set_error("%s[%d]: operand larger than 4 GiB", FN, i);
       return CA_ERR_ARG;
     }
     switch (p.epilogue) {
       case CA_EPI_BIAS:
       case CA_EPI_GELU_TANH:
-        if (p.ldc < p.N) { ca_set_error("ca_gemm_bf16[%d]: ldc < N", i); return CA_ERR_ARG; }
+        if (p.ldc < p.N) { ca_set_error("%s[%d]: ldc < N", FN, i); return CA_ERR_ARG; }
         break;
       case CA_EPI_GATE_RESIDUAL:
         if (!p.resid || !p.gate || p.ldr % 8 || p.ldc < p.N || ((uintptr_t)p.resid & 15) ||
             ((uintptr_t)p.gate & 15) || ((uintptr_t)p.gate2 & 15) || (p.gate_rows < p.M && !p.gate2)) {
-          ca_set_error("ca_gemm_bf16[%d]: GATE_RESIDUAL needs resid, gate (and gate2 when gate_rows < M), 16-byte aligned", i);
+          ca_set_error("%s[%d]: GATE_RESIDUAL needs resid, gate (and gate2 when gate_rows < M), 16-byte aligned", FN, i);
           return CA_ERR_ARG;
         }
         break;
@@ -810,20 +865,20 @@ extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems,
             p.ldc < p.n_split || (p.q_prerope && (p.ldp % 8 || p.ldp < p.n_split / 3)) ||
             (((uintptr_t)p.norm_q | (uintptr_t)p.norm_k | (uintptr_t)p.rope | (uintptr_t)p.q_prerope |
               (uintptr_t)p.out2) & 15)) {
-          ca_set_error("ca_gemm_bf16[%d]: QKV_NORM_ROPE needs the 256x256 ping-pong tile, n_split = 3*heads*128 <= N, "
-                       "norm_q/norm_k/rope (16-byte aligned) and out2 when N > n_split", i);
+          ca_set_error("%s[%d]: QKV_NORM_ROPE needs the 256x256 ping-pong tile, n_split = 3*heads*128 <= N, "
+                       "norm_q/norm_k/rope (16-byte aligned) and out2 when N > n_split", FN, i);
           return CA_ERR_ARG;
         }
         break;
       case CA_EPI_SPLIT_GELU:
         if (!p.out2 || p.n_split <= 0 || p.n_split >= p.N || p.n_split % bn || p.ld2 % 8 ||
             ((uintptr_t)p.out2 & 15) || p.ldc < p.n_split || p.ld2 < p.N - p.n_split) {
-          ca_set_error("ca_gemm_bf16[%d]: SPLIT_GELU needs out2 and 0 < n_split < N, n_split %% %d == 0", i, bn);
+          ca_set_error("%s[%d]: SPLIT_GELU needs out2 and 0 < n_split < N, n_split %% %d == 0", FN, i, bn);
           return CA_ERR_ARG;
         }
         break;
       default:
-        ca_set_error("ca_gemm_bf16[%d]: unknown epilogue %d", i, p.epilogue);
+        ca_set_error("%s[%d]: unknown epilogue %d", FN, i, p.epilogue);
         return CA_ERR_ARG;
     }
     L.p[i] = p;
@@ -838,6 +893,7 @@ extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems,
     L.p[1] = L.p[0];
   }
   hipStream_t s = (hipStream_t)stream;
+  if (fp8) return launch_pp<2, 2, true>(L, total, s);
   switch (tile) {
     case CA_TILE_PP_256x256: return launch_pp<2, 2>(L, total, s);
     case CA_TILE_PP_256x192: return launch_pp<2, 1>(L, total, s);
@@ -847,6 +903,17 @@ extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems,
     case CA_TILE_256x128: return launch<8, 2>(L, total, s);
     default: return launch<8, 1>(L, total, s);
   }
+}
+
+}  // namespace
+
+extern "C" int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
+                            ca_stream_t stream) {
+  return gemm_impl(problems, n_problems, tile, stream, false, "ca_gemm_bf16");
+}
+
+extern "C" int ca_gemm_fp8(const ca_gemm_problem *problems, int32_t n_problems, ca_stream_t stream) {
+  return gemm_impl(problems, n_problems, CA_TILE_PP_256x256, stream, true, "ca_gemm_fp8");
 }
 
 #ifdef CA_GEMM_STAMP

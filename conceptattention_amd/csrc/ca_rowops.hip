@@ -20,9 +20,34 @@ struct LnArgs {
 };
 constexpr int LN_MAXCH = 8;  // H <= 8 * 512
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// 8 floats (already divided by the row scale) -> 8 OCP e4m3 bytes (v_cvt_pk_fp8_f32, RNE; inputs clamped to
+// the largest finite e4m3 value so nothing overflows to NaN)
+constexpr float E4M3_MAX = 448.0f;
+__device__ __forceinline__ uint2 ca_pack_fp8x8(const float *y) {
+  float c[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = fminf(fmaxf(y[j], -E4M3_MAX), E4M3_MAX);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  return make_uint2((uint32_t)lo, (uint32_t)hi);
+}
+
+// FP8: the modulated row is quantised to e4m3 with one absmax scale per row (out8 row stride ldo BYTES,
+// out_scale[row] = absmax / 448): the A operand of ca_gemm_fp8.
+template <bool FP8>
 __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const bf16 *__restrict__ x, int ldx,
-                                                             bf16 *__restrict__ out, int ldo, int M, int H,
-                                                             float eps, const LnArgs A) {
+                                                             void *__restrict__ out_, int ldo, int M, int H,
+                                                             float eps, float *__restrict__ out_scale,
+                                                             const LnArgs A) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -65,7 +90,7 @@ __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const bf16 *__restr
     }
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
-  bf16 *orow = out + (size_t)row * ldo;
+  float amax = 0.f;
 #pragma unroll
   for (int c = 0; c < LN_MAXCH; ++c) {
     const int k = c * 512 + lane * 8;
@@ -78,9 +103,64 @@ __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const bf16 *__restr
         y[j] = (1.f + sc0[j]) * ((v[c][j] - mean) * rstd) + sh0[j];
         y[4 + j] = (1.f + sc1[j]) * ((v[c][4 + j] - mean) * rstd) + sh1[j];
       }
-      *(uint4 *)(orow + k) =
-          make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+      if constexpr (FP8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[c][j] = y[j];
+          amax = fmaxf(amax, fabsf(y[j]));
+        }
+      } else {
+        *(uint4 *)((bf16 *)out_ + (size_t)row * ldo + k) =
+            make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+      }
     }
+  }
+  if constexpr (FP8) {
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / E4M3_MAX) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) out_scale[row] = sc;
+    uint8_t *orow = (uint8_t *)out_ + (size_t)row * ldo;
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c) {
+      const int k = c * 512 + lane * 8;
+      if (k < H) {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = v[c][j] * inv;
+        *(uint2 *)(orow + k) = ca_pack_fp8x8(y);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Row-wise absmax quantisation bf16 -> e4m3 (weights once per model; activations that leave a GEMM or the
+// attention kernel in bf16).  One wave per row, two passes over the row (the second one hits L2).
+__global__ __launch_bounds__(256) void ca_quantize_rows_fp8_kernel(const bf16 *__restrict__ x, int ldx,
+                                                                   uint8_t *__restrict__ out, int ldo,
+                                                                   float *__restrict__ out_scale, int M, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bf16 *xr = x + (size_t)row * ldx;
+  float amax = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const bf16x8 t = *(const bf16x8 *)(xr + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf((float)t[j]));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.0f / E4M3_MAX) : 1.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) out_scale[row] = sc;
+  uint8_t *orow = out + (size_t)row * ldo;
+  for (int k = lane * 8; k < K; k += 512) {
+    const bf16x8 t = *(const bf16x8 *)(xr + k);
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = (float)t[j] * inv;
+    *(uint2 *)(orow + k) = ca_pack_fp8x8(y);
   }
 }
 
@@ -307,13 +387,15 @@ int check_launch(const char *what) {
 
 }  // namespace
 
-extern "C" int ca_ln_modulate_bf16(const void *x, int32_t ldx, void *out, int32_t ldo, int32_t M, int32_t H,
-                                   const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream) {
+namespace {
+int ln_modulate_impl(const char *FN, const void *x, int32_t ldx, void *out, int32_t ldo, float *out_scale, int32_t M,
+                     int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream) {
+  const bool fp8 = out_scale != nullptr;
   if (!x || !out || !segs || M < 1 || H < 8 || H % 8 || H > LN_MAXCH * 512 || n_segs < 1 ||
-      n_segs > CA_MAX_SEGMENTS || ldx % 8 || ldo % 8 || ldx < H || ldo < H ||
-      (((uintptr_t)x | (uintptr_t)out) & 15)) {
-    ca_set_error("ca_ln_modulate_bf16: bad arguments (M=%d H=%d n_segs=%d ldx=%d ldo=%d; need H%%8==0, H<=%d)", M, H,
-                 n_segs, ldx, ldo, LN_MAXCH * 512);
+      n_segs > CA_MAX_SEGMENTS || ldx % 8 || ldo % (fp8 ? 16 : 8) || ldx < H || ldo < H ||
+      (((uintptr_t)x | (uintptr_t)out) & 15) || ((uintptr_t)out_scale & 3)) {
+    ca_set_error("%s: bad arguments (M=%d H=%d n_segs=%d ldx=%d ldo=%d; need H%%8==0, H<=%d)", FN, M, H, n_segs, ldx,
+                 ldo, LN_MAXCH * 512);
     return CA_ERR_ARG;
   }
   LnArgs A = {};
@@ -322,19 +404,51 @@ extern "C" int ca_ln_modulate_bf16(const void *x, int32_t ldx, void *out, int32_
   for (int i = 0; i < n_segs; ++i) {
     if (!segs[i].shift || !segs[i].scale || segs[i].row_end < prev ||
         (((uintptr_t)segs[i].shift | (uintptr_t)segs[i].scale) & 15)) {
-      ca_set_error("ca_ln_modulate_bf16: segment %d invalid (row_end must be non-decreasing, vectors 16-byte aligned)", i);
+      ca_set_error("%s: segment %d invalid (row_end must be non-decreasing, vectors 16-byte aligned)", FN, i);
       return CA_ERR_ARG;
     }
     prev = segs[i].row_end;
     A.seg[i] = segs[i];
   }
   if (prev < M) {
-    ca_set_error("ca_ln_modulate_bf16: segments cover %d rows, M=%d", prev, M);
+    ca_set_error("%s: segments cover %d rows, M=%d", FN, prev, M);
     return CA_ERR_ARG;
   }
-  hipLaunchKernelGGL(ca_ln_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16 *)x,
-                     ldx, (bf16 *)out, ldo, M, H, eps, A);
-  return check_launch("ca_ln_modulate_bf16");
+  if (fp8)
+    hipLaunchKernelGGL(ca_ln_modulate_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16 *)x, ldx, out, ldo, M, H, eps, out_scale, A);
+  else
+    hipLaunchKernelGGL(ca_ln_modulate_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16 *)x, ldx, out, ldo, M, H, eps, (float *)nullptr, A);
+  return check_launch(FN);
+}
+}  // namespace
+
+extern "C" int ca_ln_modulate_bf16(const void *x, int32_t ldx, void *out, int32_t ldo, int32_t M, int32_t H,
+                                   const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream) {
+  return ln_modulate_impl("ca_ln_modulate_bf16", x, ldx, out, ldo, nullptr, M, H, segs, n_segs, eps, stream);
+}
+
+extern "C" int ca_ln_modulate_fp8(const void *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale, int32_t M,
+                                  int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps,
+                                  ca_stream_t stream) {
+  if (!out_scale) {
+    ca_set_error("ca_ln_modulate_fp8: out_scale is NULL");
+    return CA_ERR_ARG;
+  }
+  return ln_modulate_impl("ca_ln_modulate_fp8", x, ldx, out8, ldo, out_scale, M, H, segs, n_segs, eps, stream);
+}
+
+extern "C" int ca_quantize_rows_fp8(const void *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale, int32_t M,
+                                    int32_t K, ca_stream_t stream) {
+  if (!x || !out8 || !out_scale || M < 1 || K < 8 || K % 8 || ldx % 8 || ldo % 8 || ldx < K || ldo < K ||
+      (((uintptr_t)x) & 15) || (((uintptr_t)out8) & 7) || ((uintptr_t)out_scale & 3)) {
+    ca_set_error("ca_quantize_rows_fp8: bad arguments (M=%d K=%d ldx=%d ldo=%d; need K%%8==0, ld%%8==0)", M, K, ldx, ldo);
+    return CA_ERR_ARG;
+  }
+  hipLaunchKernelGGL(ca_quantize_rows_fp8_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16 *)x, ldx, (uint8_t *)out8, ldo, out_scale, M, K);
+  return check_launch("ca_quantize_rows_fp8");
 }
 
 extern "C" int ca_qknorm_rope_bf16(void *qkv, int32_t ld, int32_t M, int32_t num_heads,

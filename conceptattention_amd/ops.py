@@ -52,13 +52,24 @@ class Gemm:
     norm_k: Optional[torch.Tensor] = None  # optional bf16 [M, heads*128] pre-RoPE q output
     rope: Optional[torch.Tensor] = None
     q_prerope: Optional[torch.Tensor] = None
+    a_scale: Optional[torch.Tensor] = None  # fp8 mode: a, w are uint8 (e4m3 bytes) with fp32 row scales
+    w_scale: Optional[torch.Tensor] = None  # ([M] and [N]); the launch then goes to ca_gemm_fp8
 
 
 def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
     lib = L.load()
     arr = (L.GemmProblem * len(problems))()
+    fp8 = problems[0].a.dtype == torch.uint8
+    op_dtype = torch.uint8 if fp8 else torch.bfloat16
     for i, g in enumerate(problems):
-        a, w, out = _chk(g.a, torch.bfloat16, "a"), _chk(g.w, torch.bfloat16, "w"), _chk(g.out, torch.bfloat16, "out")
+        a, w, out = _chk(g.a, op_dtype, "a"), _chk(g.w, op_dtype, "w"), _chk(g.out, torch.bfloat16, "out")
+        if fp8:
+            if g.a_scale is None or g.w_scale is None:
+                raise ValueError(f"gemm[{i}]: fp8 operands need a_scale and w_scale")
+            sa, sw = _chk(g.a_scale, torch.float32, "a_scale"), _chk(g.w_scale, torch.float32, "w_scale")
+            if sa.numel() != a.shape[0] or sw.numel() != w.shape[0] or not (sa.is_contiguous() and sw.is_contiguous()):
+                raise ValueError(f"gemm[{i}]: a_scale must be contiguous [M], w_scale contiguous [N]")
+            arr[i].a_scale, arr[i].w_scale = sa.data_ptr(), sw.data_ptr()
         if a.dim() != 2 or w.dim() != 2 or out.dim() != 2 or a.shape[1] != w.shape[1] or a.shape[0] != out.shape[0]:
             raise ValueError(f"gemm[{i}]: shape mismatch a{tuple(a.shape)} w{tuple(w.shape)} out{tuple(out.shape)}")
         p = arr[i]
@@ -91,6 +102,15 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
             if g.out2 is None:
                 raise ValueError(f"gemm[{i}]: SPLIT_GELU needs out2")
             p.out2, p.ld2, p.n_split = _chk(g.out2, torch.bfloat16, "out2").data_ptr(), g.out2.stride(0), g.n_split
+    if fp8:
+        if tile not in (L.TILE_AUTO, L.TILE_PP_256x256):
+            raise ValueError("gemm: fp8 operands run on the 256x256 ping-pong tile only")
+        if _gemm_hook is not None:
+            _gemm_hook(arr, L.TILE_PP_256x256,
+                       lambda: L.check(lib.ca_gemm_fp8(arr, len(problems), _stream()), "ca_gemm_fp8"))
+            return
+        L.check(lib.ca_gemm_fp8(arr, len(problems), _stream()), "ca_gemm_fp8")
+        return
     if _gemm_hook is not None:
         if tile == L.TILE_AUTO:
             tile = lib.ca_gemm_auto_tile(arr, len(problems))
@@ -157,10 +177,15 @@ def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] =
     L.check(lib.ca_attn_fwd_bf16(arr, len(problems), num_heads, scale, _stream()), "ca_attn_fwd_bf16")
 
 
-def ln_modulate(x, out, segments, eps: float = 1e-6) -> None:
-    """segments: [(row_end, shift fp32[H], scale fp32[H]), ...] covering all rows of x."""
+def ln_modulate(x, out, segments, eps: float = 1e-6, out_scale=None) -> None:
+    """segments: [(row_end, shift fp32[H], scale fp32[H]), ...] covering all rows of x.
+    With ``out`` uint8 and ``out_scale`` fp32 [M] the result is quantised to e4m3 per row (ca_ln_modulate_fp8)."""
     lib = L.load()
-    _chk(x, torch.bfloat16, "x"), _chk(out, torch.bfloat16, "out")
+    fp8 = out.dtype == torch.uint8
+    _chk(x, torch.bfloat16, "x"), _chk(out, torch.uint8 if fp8 else torch.bfloat16, "out")
+    if fp8 and (out_scale is None or out_scale.dtype != torch.float32 or out_scale.numel() != x.shape[0]
+                or not out_scale.is_contiguous()):
+        raise ValueError("ln_modulate: fp8 output needs a contiguous fp32 out_scale [M]")
     if len(segments) > L.MAX_SEGMENTS:
         raise ValueError("ln_modulate: too many segments")
     arr = (L.ModSegment * len(segments))()
@@ -168,8 +193,31 @@ def ln_modulate(x, out, segments, eps: float = 1e-6) -> None:
         arr[i].row_end = row_end
         arr[i].shift = _chk(shift, torch.float32, "shift").data_ptr()
         arr[i].scale = _chk(scale, torch.float32, "scale").data_ptr()
+    if fp8:
+        L.check(lib.ca_ln_modulate_fp8(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), out_scale.data_ptr(),
+                                       x.shape[0], x.shape[1], arr, len(segments), eps, _stream()),
+                "ca_ln_modulate_fp8")
+        return
     L.check(lib.ca_ln_modulate_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
                                     arr, len(segments), eps, _stream()), "ca_ln_modulate_bf16")
+
+
+def quantize_rows_fp8(x, out=None, out_scale=None):
+    """Row-wise absmax quantisation bf16 [M,K] -> (uint8 e4m3 [M,K], fp32 scale [M])."""
+    lib = L.load()
+    _chk(x, torch.bfloat16, "x")
+    if x.dim() != 2:
+        raise ValueError("quantize_rows_fp8: expected a 2-D tensor")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    if out_scale is None:
+        out_scale = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+    _chk(out, torch.uint8, "out"), _chk(out_scale, torch.float32, "out_scale")
+    if tuple(out.shape) != tuple(x.shape) or out_scale.numel() != x.shape[0] or not out_scale.is_contiguous():
+        raise ValueError("quantize_rows_fp8: out must match x, out_scale must be contiguous [M]")
+    L.check(lib.ca_quantize_rows_fp8(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), out_scale.data_ptr(),
+                                     x.shape[0], x.shape[1], _stream()), "ca_quantize_rows_fp8")
+    return out, out_scale
 
 
 def qknorm_rope(qkv, num_heads, segments, rope_cos_sin, q_prerope=None) -> None:

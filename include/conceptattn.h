@@ -86,6 +86,8 @@ typedef struct {
   const void *norm_k;/* bf16 [128] key_norm.scale */
   const float *rope; /* fp32 [M,64,2] (cos,sin) for this problem's rows */
   void *q_prerope;   /* optional bf16 [M, heads*128], row stride ldp: normalised pre-RoPE q */
+  const float *a_scale; /* ca_gemm_fp8 only: fp32 [M], dequantisation scale of each row of A */
+  const float *w_scale; /* ca_gemm_fp8 only: fp32 [N], dequantisation scale of each row of W */
   int32_t M, N, K;
   int32_t lda, ldw, ldc, ldr, ld2;
   int32_t n_split;   /* SPLIT_GELU: multiple of the tile width; QKV_NORM_ROPE: 3*heads*128 */
@@ -97,6 +99,15 @@ typedef struct {
 int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile, ca_stream_t stream);
 /* The CA_TILE_* value CA_TILE_AUTO resolves to for these problems (> 0), or CA_ERR_ARG. No launch. */
 int ca_gemm_auto_tile(const ca_gemm_problem *problems, int32_t n_problems);
+
+/* The same grouped GEMM and epilogues on OCP fp8 (e4m3fn) operands, for the reduced-precision sweep mode
+ * (BASELINE.json configs[4]; no counterpart in the reference, which is bf16 throughout -- SURVEY.md 8f-2):
+ *   out[m,n] = epi( a_scale[m] * w_scale[n] * sum_k A8[m,k] * W8[n,k] + bias[n] )
+ * A8/W8 are e4m3 bytes produced by ca_quantize_rows_fp8 (absmax per row), lda/ldw in elements (= bytes),
+ * K % 128 == 0, lda/ldw % 16 == 0; the accumulation is fp32 (v_mfma_scale_f32_16x16x128_f8f6f4 with unit
+ * block scales), out/resid/bias/gates stay bf16/fp32 as above.  256x256 ping-pong tile only (N % 256 == 0).
+ */
+int ca_gemm_fp8(const ca_gemm_problem *problems, int32_t n_problems, ca_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flash attention forward, head_dim 128, no mask:  out = softmax(q k^T * scale) v  per head.
@@ -139,6 +150,14 @@ typedef struct {
 
 int ca_ln_modulate_bf16(const void *x, int32_t ldx, void *out, int32_t ldo, int32_t M, int32_t H,
                         const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream);
+/* Same, with the result quantised for ca_gemm_fp8: out8 = e4m3 bytes (row stride ldo bytes, % 16),
+ * out_scale[row] = absmax(row) / 448 (fp32 [M]). */
+int ca_ln_modulate_fp8(const void *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale, int32_t M,
+                       int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream);
+/* Row-wise absmax quantisation bf16 [M,K] -> e4m3 [M,K] + fp32 scale per row (weights once per model;
+ * activations between two fp8 GEMMs). */
+int ca_quantize_rows_fp8(const void *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale, int32_t M,
+                         int32_t K, ca_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * QK-RMSNorm + RoPE, in place on the q and k thirds of a [M, 3*H*128] projection buffer.
