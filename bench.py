@@ -41,6 +41,7 @@ def step_flops(p, L, T, C):
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense block-scaled fp8 (v_mfma_scale_f32_16x16x128_f8f6f4), same table
 
 
 def cpu_baseline(p, L, T, C, steps_per_call, n_layers_double, n_layers_single):
@@ -97,6 +98,9 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--streams", type=int, default=2,
                     help="independent work items kept in flight per GPU on separate HIP streams (throughput mode)")
+    ap.add_argument("--precision", choices=("bf16", "fp8"), default="bf16",
+                    help="fp8: the large projections run on e4m3 operands (reduced-precision mode of "
+                         "BASELINE.json configs[4]; NOT the headline metric, which is bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-launch HIP-event timing of the GEMM kernel (roofline.achieved then "
@@ -124,7 +128,8 @@ def main():
     p = configs[args.model]
     C, T = args.concepts, T5_TOKENS[args.model]
     Lp = (args.size // 16) ** 2
-    pipe = ConceptAttentionFluxPipeline(args.model, device=dev, weights="synthetic", weight_seed=0)
+    pipe = ConceptAttentionFluxPipeline(args.model, device=dev, weights="synthetic", weight_seed=0,
+                                        precision=args.precision)
     layer_indices = list(range(15, 19))
     n_timed = world * args.steps  # timed work items 0..n_timed-1, item i on rank i % world
 
@@ -226,7 +231,9 @@ def main():
         flops_call = args.diffusion_steps * step_flops(p, Lp, T, C) + \
             len(layer_indices) * args.diffusion_steps * 2 * (2 * C * Lp * p.hidden_size)
         path_tflops = flops_call * calls / elapsed / 1e12 / world  # per GPU
-        roof = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+        fp8 = args.precision == "fp8"
+        roof = {"bound": "mfma", "peak": MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "traffic": None}
         if records:
             torch.cuda.synchronize()
             by_tile = {}
@@ -240,6 +247,8 @@ def main():
                      3: "ca_gemm_kernel<8,2> (256x128x64)", 4: "ca_gemm_kernel<8,1> (256x64x64)",
                      5: "ca_gemm_pp_kernel<2,2> (256x256x64 ping-pong)", 6: "ca_gemm_pp_kernel<1,1> (256x128x64 ping-pong)",
                      7: "ca_gemm_pp_kernel<2,1> (256x192x64 ping-pong)"}
+            if fp8:
+                names[5] = "ca_gemm_pp_kernel<2,2,fp8> (256x256x128 ping-pong, e4m3)"
             roof.update(kernel=names.get(tile, str(tile)), launches=n, avg_launch_us=sec / n * 1e6,
                         flops_per_launch=fl / n, achieved=fl / sec / 1e12,
                         timed_on="last timed step of rank 0",
@@ -252,7 +261,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
             key = roof.get("kernel", "").split(" ")[0]
-            if key in pmc:
+            if key in pmc and not fp8:
                 roof["traffic"] = pmc[key]["bytes_per_launch"]
                 roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)"
         except (OSError, KeyError, ValueError):
@@ -260,6 +269,10 @@ def main():
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["path_achieved"] = path_tflops
         roof["path_frac"] = path_tflops / MFMA_BF16_PEAK_TFLOPS
+        if fp8:
+            roof["note"] = ("path_frac and concept_attention_block.mfma_frac are fractions of the 2.5 PFLOP/s bf16 "
+                            "peak (attention and the small kernels stay bf16); frac is the e4m3 GEMM kernel "
+                            "against the 5 PFLOP/s fp8 peak")
         res = {
             "metric": "concept-heatmaps/sec (1024x1024, 4 concepts, 4 steps)",
             "value": calls * C / elapsed,
@@ -267,8 +280,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.model} bf16 {args.size}x{args.size}, {C} concepts, "
+            "dtype": "fp8(e4m3 projections)+bf16" if fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.precision} {args.size}x{args.size}, {C} concepts, "
                                    f"{args.diffusion_steps} diffusion steps, {T} text tokens "
                                    "(generate_image-equivalent call; random-init weights, synthetic latents/embeddings)",
                        "calls_per_step_per_gpu": 1, "heatmap_layers": layer_indices,

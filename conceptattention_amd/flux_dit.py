@@ -53,6 +53,7 @@ class FluxWeights:
         self.device = torch.device(device)
         H = params.hidden_size
         self.tensors: dict[str, torch.Tensor] = {}
+        self.fp8 = None  # name -> (e4m3 bytes, fp32 row scales) of the large projections, built on first fp8 use
         mod_names = []
         for i in range(params.depth):
             mod_names += [(f"double_blocks.{i}.img_mod.lin", 6 * H), (f"double_blocks.{i}.txt_mod.lin", 6 * H)]
@@ -86,6 +87,7 @@ class FluxWeights:
         """Copy tensors in (any float dtype / device).  Same (missing, unexpected) semantics as
         nn.Module.load_state_dict (the reference calls it with strict=False,
         concept_attention/image_generator.py:44)."""
+        self.fp8 = None
         missing = [k for k in self.tensors if k not in sd]
         unexpected = [k for k in sd if k not in self.tensors]
         if strict and (missing or unexpected):
@@ -102,6 +104,7 @@ class FluxWeights:
         the GPU (fast, 23.8 GB for full Flux); False draws on the CPU generator so the values
         are identical to ``weights.synthetic_state_dict`` (used by the parity tests)."""
         dev = self.device if on_device else "cpu"
+        self.fp8 = None
         for name, t in iter_synthetic_state_dict(self.params, seed=seed, device=dev, dtype=torch.float32):
             self.tensors[name].copy_(t)
         return self
@@ -127,7 +130,7 @@ class HipFluxDiT:
     """Drop-in for the reference's ``ModifiedFluxDiT`` instance on the hot path (inference only)."""
 
     def __init__(self, params: FluxParams, device="cuda:0", weights: Optional[FluxWeights] = None,
-                 attention_block_class=None):
+                 attention_block_class=None, precision: str = "bf16"):
         # attention_block_class is accepted for signature compatibility with
         # ModifiedFluxDiT(params, attention_block_class=...) (modified_flux_dit.py:34); the HIP
         # path has exactly one block implementation.
@@ -145,6 +148,35 @@ class HipFluxDiT:
         self._rope_key = None
         self._mod_cur = None
         self._mod_steps = None
+        self.set_precision(precision)
+
+    # ---- reduced-precision mode (BASELINE.json configs[4]; no counterpart in the reference)
+    FP8_LINEARS = ("img_attn.qkv", "txt_attn.qkv", "img_attn.proj", "txt_attn.proj", "img_mlp.0", "txt_mlp.0",
+                   "img_mlp.2", "txt_mlp.2", "linear1", "linear2")
+
+    def set_precision(self, precision: str):
+        """"bf16" (default; the parity path) or "fp8": the six large projections of every block run on e4m3
+        operands (weights quantised once per output channel, activations per token by the producing
+        kernel), accumulation fp32, everything else unchanged.  See DESIGN.md "fp8 mode" for the measured
+        heat-map deviation from the bf16 path."""
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
+        self.precision = precision
+        return self
+
+    def _fp8_weights(self):
+        W = self.weights
+        if W.fp8 is None:
+            W.fp8 = {name: ops.quantize_rows_fp8(t) for name, t in W.tensors.items()
+                     if name.endswith(".weight") and name.rsplit(".", 1)[0].split(".", 2)[-1] in self.FP8_LINEARS}
+        return W.fp8
+
+    def _gemm(self, fp8, a, a8, a8s, wname, bias, out, *args, **kw):
+        """One problem of a grouped launch in the current precision."""
+        if fp8:
+            q, sc = self._fp8_weights()[wname]
+            return ops.Gemm(a8, q, bias, out, *args, a_scale=a8s, w_scale=sc, **kw)
+        return ops.Gemm(a, self.weights[wname], bias, out, *args, **kw)
 
     # ---- nn.Module-like surface the reference's loader touches (image_generator.py:37-44,183,194)
     def load_state_dict(self, sd, strict: bool = True, assign: bool = False):
@@ -164,7 +196,7 @@ class HipFluxDiT:
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, L_img: int, T: int, C: int):
-        key = (L_img, T, C)
+        key = (L_img, T, C, self.precision)
         if self._ws_key == key:
             return
         p, dev = self.params, self.device
@@ -190,6 +222,12 @@ class HipFluxDiT:
         self.VEC = torch.zeros(2, H, **f32)
         self.MOD = torch.zeros(2, self.weights.mod_rows, **f32)
         self.LOGITS = torch.zeros(max(C, 1), L_img, **f32)
+        if self.precision == "fp8":   # e4m3 images of the GEMM inputs + one fp32 scale per row
+            u8 = dict(device=dev, dtype=torch.uint8)
+            self.XM8, self.XMS = torch.zeros(n, H, **u8), torch.zeros(n, **f32)
+            self.ATT8, self.ATTS = torch.zeros(n, H, **u8), torch.zeros(n, **f32)
+            self.HID8, self.HIDS = torch.zeros(n, MLP, **u8), torch.zeros(n, **f32)
+            self.CAT8, self.CATS = torch.zeros(T + L_img, H + MLP, **u8), torch.zeros(T + L_img, **f32)
         self._ws_key = key
         self._rope_key = None
 
@@ -367,21 +405,34 @@ class HipFluxDiT:
         b = f"double_blocks.{i}."
         im, tm = b + "img_mod.lin", b + "txt_mod.lin"
         capture = return_vectors or (heatmaps is not None and i in heatmaps.layer_indices)
+        fp8 = self.precision == "fp8"
+        if fp8:
+            XM8, XMS, ATT8, ATTS, HID8, HIDS = self.XM8, self.XMS, self.ATT8, self.ATTS, self.HID8, self.HIDS
+            xm_out = dict(out=XM8, out_scale=XMS)
+        else:
+            XM8 = XMS = ATT8 = ATTS = HID8 = HIDS = None
+            xm_out = dict(out=XM)
+
+        def rows(t, lo, hi):
+            return None if t is None else t[lo:hi]
+        G = self._gemm
         # K4: LayerNorm + (1+scale)*x+shift, three row segments (:88-89,94-95,100-101)
-        ops.ln_modulate(X, XM, [(C, self._mod(tm, 1, 0), self._mod(tm, 1, 1)),
-                                (CT, self._mod(tm, 0, 0), self._mod(tm, 0, 1)),
-                                (n, self._mod(im, 0, 0), self._mod(im, 0, 1))])
+        ops.ln_modulate(X, segments=[(C, self._mod(tm, 1, 0), self._mod(tm, 1, 1)),
+                                     (CT, self._mod(tm, 0, 0), self._mod(tm, 0, 1)),
+                                     (n, self._mod(im, 0, 0), self._mod(im, 0, 1))], **xm_out)
         # K5+K6+K7: qkv projections (image stream + [concept|text] stream in one grouped launch) with
         # QK-RMSNorm and RoPE fused into the epilogue; pre-RoPE q kept for the cross-attention maps
         qpre = self.QPRE if capture else None
-        ops.gemm([ops.Gemm(XM[CT:], W[b + "img_attn.qkv.weight"], W.tensors.get(b + "img_attn.qkv.bias"), QKV[CT:],
-                           L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
-                           norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[CT:],
-                           q_prerope=None if qpre is None else qpre[CT:]),
-                  ops.Gemm(XM[:CT], W[b + "txt_attn.qkv.weight"], W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:CT],
-                           L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
-                           norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:CT],
-                           q_prerope=None if qpre is None else qpre[:CT])])
+        ops.gemm([G(fp8, XM[CT:], rows(XM8, CT, n), rows(XMS, CT, n), b + "img_attn.qkv.weight",
+                    W.tensors.get(b + "img_attn.qkv.bias"), QKV[CT:],
+                    L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
+                    norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[CT:],
+                    q_prerope=None if qpre is None else qpre[CT:]),
+                  G(fp8, XM[:CT], rows(XM8, 0, CT), rows(XMS, 0, CT), b + "txt_attn.qkv.weight",
+                    W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:CT],
+                    L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
+                    norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:CT],
+                    q_prerope=None if qpre is None else qpre[:CT])])
         # K8+K9: joint text+image attention and the concept rows in one launch
         probs = [ops.Attn(qs[C:], ATT[C:], ks[C:], vs[C:])]
         if C > 0:
@@ -397,23 +448,33 @@ class HipFluxDiT:
         ops.attention(probs, NH)
         if capture:
             self._capture(out, i, C, CT, n, NH, return_vectors, heatmaps)
+        if fp8:
+            ops.quantize_rows_fp8(ATT, ATT8, ATTS)
         # K12: proj + gated residual (:194,198,201); concept rows use txt weights + concept gate
-        ops.gemm([ops.Gemm(ATT[CT:], W[b + "img_attn.proj.weight"], W[b + "img_attn.proj.bias"], X[CT:],
-                           L.EPI_GATE_RESIDUAL, resid=X[CT:], gate=self._mod(im, 0, 2)),
-                  ops.Gemm(ATT[:CT], W[b + "txt_attn.proj.weight"], W[b + "txt_attn.proj.bias"], X[:CT],
-                           L.EPI_GATE_RESIDUAL, resid=X[:CT], gate=self._mod(tm, 1, 2), gate2=self._mod(tm, 0, 2),
-                           gate_rows=C)])
+        ops.gemm([G(fp8, ATT[CT:], rows(ATT8, CT, n), rows(ATTS, CT, n), b + "img_attn.proj.weight",
+                    W[b + "img_attn.proj.bias"], X[CT:],
+                    L.EPI_GATE_RESIDUAL, resid=X[CT:], gate=self._mod(im, 0, 2)),
+                  G(fp8, ATT[:CT], rows(ATT8, 0, CT), rows(ATTS, 0, CT), b + "txt_attn.proj.weight",
+                    W[b + "txt_attn.proj.bias"], X[:CT],
+                    L.EPI_GATE_RESIDUAL, resid=X[:CT], gate=self._mod(tm, 1, 2), gate2=self._mod(tm, 0, 2),
+                    gate_rows=C)])
         # K13: LN + modulate + MLP + gated residual (:196,199,202)
-        ops.ln_modulate(X, XM, [(C, self._mod(tm, 1, 3), self._mod(tm, 1, 4)),
-                                (CT, self._mod(tm, 0, 3), self._mod(tm, 0, 4)),
-                                (n, self._mod(im, 0, 3), self._mod(im, 0, 4))])
-        ops.gemm([ops.Gemm(XM[CT:], W[b + "img_mlp.0.weight"], W[b + "img_mlp.0.bias"], HID[CT:], L.EPI_GELU_TANH),
-                  ops.Gemm(XM[:CT], W[b + "txt_mlp.0.weight"], W[b + "txt_mlp.0.bias"], HID[:CT], L.EPI_GELU_TANH)])
-        ops.gemm([ops.Gemm(HID[CT:], W[b + "img_mlp.2.weight"], W[b + "img_mlp.2.bias"], X[CT:],
-                           L.EPI_GATE_RESIDUAL, resid=X[CT:], gate=self._mod(im, 0, 5)),
-                  ops.Gemm(HID[:CT], W[b + "txt_mlp.2.weight"], W[b + "txt_mlp.2.bias"], X[:CT],
-                           L.EPI_GATE_RESIDUAL, resid=X[:CT], gate=self._mod(tm, 1, 5), gate2=self._mod(tm, 0, 5),
-                           gate_rows=C)])
+        ops.ln_modulate(X, segments=[(C, self._mod(tm, 1, 3), self._mod(tm, 1, 4)),
+                                     (CT, self._mod(tm, 0, 3), self._mod(tm, 0, 4)),
+                                     (n, self._mod(im, 0, 3), self._mod(im, 0, 4))], **xm_out)
+        ops.gemm([G(fp8, XM[CT:], rows(XM8, CT, n), rows(XMS, CT, n), b + "img_mlp.0.weight",
+                    W[b + "img_mlp.0.bias"], HID[CT:], L.EPI_GELU_TANH),
+                  G(fp8, XM[:CT], rows(XM8, 0, CT), rows(XMS, 0, CT), b + "txt_mlp.0.weight",
+                    W[b + "txt_mlp.0.bias"], HID[:CT], L.EPI_GELU_TANH)])
+        if fp8:
+            ops.quantize_rows_fp8(HID, HID8, HIDS)
+        ops.gemm([G(fp8, HID[CT:], rows(HID8, CT, n), rows(HIDS, CT, n), b + "img_mlp.2.weight",
+                    W[b + "img_mlp.2.bias"], X[CT:],
+                    L.EPI_GATE_RESIDUAL, resid=X[CT:], gate=self._mod(im, 0, 5)),
+                  G(fp8, HID[:CT], rows(HID8, 0, CT), rows(HIDS, 0, CT), b + "txt_mlp.2.weight",
+                    W[b + "txt_mlp.2.bias"], X[:CT],
+                    L.EPI_GATE_RESIDUAL, resid=X[:CT], gate=self._mod(tm, 1, 5), gate2=self._mod(tm, 0, 5),
+                    gate_rows=C)])
 
     def _single_block(self, i, C, T, Li):
         """ModifiedSingleStreamBlock.forward (modified_single_stream_block.py:43-56) on the
@@ -423,13 +484,23 @@ class HipFluxDiT:
         xs, xms, qkvs, CAT = self.X[C:], self.XM[C:], self.QKV[C:], self.CAT
         b = f"single_blocks.{i}."
         m = b + "modulation.lin"
-        ops.ln_modulate(xs, xms, [(T + Li, self._mod(m, 0, 0), self._mod(m, 0, 1))])
-        ops.gemm([ops.Gemm(xms, W[b + "linear1.weight"], W[b + "linear1.bias"], qkvs, L.EPI_QKV_NORM_ROPE,
-                           out2=CAT[:, H:], n_split=3 * H, norm_q=W[b + "norm.query_norm.scale"],
-                           norm_k=W[b + "norm.key_norm.scale"], rope=self.ROPE[C:])])
+        fp8 = self.precision == "fp8"
+        G = self._gemm
+        segs = [(T + Li, self._mod(m, 0, 0), self._mod(m, 0, 1))]
+        if fp8:
+            xm8, xms8 = self.XM8[C:], self.XMS[C:]
+            ops.ln_modulate(xs, xm8, segs, out_scale=xms8)
+        else:
+            xm8 = xms8 = None
+            ops.ln_modulate(xs, xms, segs)
+        ops.gemm([G(fp8, xms, xm8, xms8, b + "linear1.weight", W[b + "linear1.bias"], qkvs, L.EPI_QKV_NORM_ROPE,
+                    out2=CAT[:, H:], n_split=3 * H, norm_q=W[b + "norm.query_norm.scale"],
+                    norm_k=W[b + "norm.key_norm.scale"], rope=self.ROPE[C:])])
         ops.attention([ops.Attn(qkvs[:, :H], CAT[:, :H], qkvs[:, H:2 * H], qkvs[:, 2 * H:])], NH)
-        ops.gemm([ops.Gemm(CAT, W[b + "linear2.weight"], W[b + "linear2.bias"], xs, L.EPI_GATE_RESIDUAL,
-                           resid=xs, gate=self._mod(m, 0, 2))])
+        if fp8:
+            ops.quantize_rows_fp8(CAT, self.CAT8, self.CATS)
+        ops.gemm([G(fp8, CAT, self.CAT8 if fp8 else None, self.CATS if fp8 else None, b + "linear2.weight",
+                    W[b + "linear2.bias"], xs, L.EPI_GATE_RESIDUAL, resid=xs, gate=self._mod(m, 0, 2))])
 
     forward = __call__
 

@@ -69,9 +69,10 @@ def colorize_heatmaps(heatmaps: np.ndarray, cmap: str = "plasma") -> list:
 class ConceptAttentionFluxPipeline:
     def __init__(self, model_name: str = "flux-schnell", offload_model: bool = False, device="cuda:0",
                  weights="synthetic", weight_seed: int = 0, text_encoder=None, autoencoder=None,
-                 params=None, n_text_tokens: Optional[int] = None):
+                 params=None, n_text_tokens: Optional[int] = None, precision: str = "bf16"):
         """model_name / offload_model / device as in the reference (:100-113).  ``weights`` is
-        "synthetic" (seeded random init), a path to a flux1-*.safetensors file, or a state dict."""
+        "synthetic" (seeded random init), a path to a flux1-*.safetensors file, or a state dict.
+        ``precision="fp8"`` runs the large projections on e4m3 operands (HipFluxDiT.set_precision)."""
         if params is None and model_name not in configs:
             raise KeyError(model_name)
         self.model_name = model_name
@@ -86,6 +87,7 @@ class ConceptAttentionFluxPipeline:
                                             autoencoder=autoencoder, params=self.params,
                                             n_text_tokens=n_text_tokens)
         self.model = self.flux_generator.model
+        self.model.set_precision(precision)
         self._replicas = [self.model]  # activation sets that share self.model's weights (one per stream)
         self._streams = []
         self.text_encoder = self.flux_generator.text_encoder
@@ -142,7 +144,8 @@ class ConceptAttentionFluxPipeline:
         identical to ``generate_on_device`` item by item.  Returns [(img, heat, cross), ...]."""
         n_streams = max(1, min(n_streams, len(items)))
         while len(self._replicas) < n_streams:
-            self._replicas.append(HipFluxDiT(self.params, self.device, weights=self.model.weights))
+            self._replicas.append(HipFluxDiT(self.params, self.device, weights=self.model.weights,
+                                             precision=self.model.precision))
         while len(self._streams) < n_streams:
             self._streams.append(torch.cuda.Stream(device=self.device))
         cur = torch.cuda.current_stream(self.device)

@@ -242,3 +242,34 @@ def test_full_size_double_block_dev_token_counts(golden):
     assert maxabs(m.X[CT:][rows], g["img_out_rows"]) < 6e-2
     assert maxabs(m.X[C:CT][::16], g["txt_out"]) < 6e-2
     assert maxabs(m.X[:C], g["concepts_out"][0]) < 6e-2
+
+
+def test_tiny_model_fp8_mode_tracks_bf16():
+    """fp8 mode (e4m3 projections): no reference exists, so the check is against the bf16 path of the same
+    kernels on the tiny model -- same shapes and keys, heat maps within 3e-2 (e4m3 has a 2^-4 relative
+    step), pred within 10 % rms; and switching back restores the bf16 result bit for bit."""
+    p = tiny_params()
+    m = HipFluxDiT(p, DEV)
+    m.weights.init_synthetic(3, on_device=False)
+    inp = synthetic_inputs(p, 256, 256, 8, 3, seed=5, dtype=torch.bfloat16)
+    from conceptattention_amd import sampling
+    x = {k: v.to(DEV) for k, v in inp.items()}
+    kw = dict(img=sampling.patchify(x["latent"]), img_ids=x["img_ids"], txt=x["txt"], txt_ids=x["txt_ids"],
+              concepts=x["concepts"], concept_ids=x["concept_ids"], concept_vec=x["concept_vec"], y=x["vec"],
+              timesteps=torch.full((1,), 0.7, device=DEV), guidance=torch.zeros(1, device=DEV))
+    pred_a, d_a = m(**kw)
+    m.set_precision("fp8")
+    pred_b, d_b = m(**kw)
+    m.set_precision("bf16")
+    pred_c, d_c = m(**kw)
+    assert torch.equal(pred_a, pred_c) and all(torch.equal(d_a[k], d_c[k]) for k in d_a)
+    assert d_b.keys() == d_a.keys() and all(d_b[k].shape == d_a[k].shape for k in d_a)
+    rel = ((pred_b.float() - pred_a.float()).norm() / pred_a.float().norm()).item()
+    assert 0 < rel < 0.10, rel
+    from conceptattention_amd.heatmaps import compute_heatmaps_from_vectors
+    layers = list(range(p.depth))
+    ha = compute_heatmaps_from_vectors(d_a["output_space_image_vectors"][None], d_a["output_space_concept_vectors"][None],
+                                       layers, [0])
+    hb = compute_heatmaps_from_vectors(d_b["output_space_image_vectors"][None], d_b["output_space_concept_vectors"][None],
+                                       layers, [0])
+    assert (ha - hb).abs().max().item() < 3e-2

@@ -123,3 +123,26 @@ def bench_qkv_fusion():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "qkv":
     bench_qkv_fusion()
+
+
+def bench_gemm_fp8(M, N, K, epi=L.EPI_BIAS, name=""):
+    a, w, b = rnd(M, K), rnd(N, K, scale=0.02), rnd(N)
+    qa, sa = ops.quantize_rows_fp8(a)
+    qw, sw = ops.quantize_rows_fp8(w)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    kw = dict(resid=out, gate=torch.randn(N, device=dev)) if epi == L.EPI_GATE_RESIDUAL else {}
+    t = timeit(lambda: ops.gemm([ops.Gemm(qa, qw, b, out, epi, a_scale=sa, w_scale=sw, **kw)]))
+    tq = timeit(lambda: ops.quantize_rows_fp8(a, qa, sa))
+    print(f"gemm-fp8 {name:8s} M={M:5d} N={N:5d} K={K:5d} epi={epi}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s"
+          f"   (quantising A: {tq*1e6:6.1f} us, {M*K*3/tq/1e9:6.0f} GB/s)", flush=True)
+    return t
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "fp8":
+    print(torch.cuda.get_device_name(0))
+    for (M, N, K, epi, name) in [(4096, 9216, 3072, L.EPI_BIAS, "qkv"), (4096, 3072, 3072, L.EPI_GATE_RESIDUAL, "proj"),
+                                 (4096, 12288, 3072, L.EPI_GELU_TANH, "mlp0"), (4096, 3072, 12288, L.EPI_GATE_RESIDUAL, "mlp2"),
+                                 (4352, 21504, 3072, L.EPI_BIAS, "linear1"), (4352, 3072, 15360, L.EPI_GATE_RESIDUAL, "linear2"),
+                                 (8192, 8192, 8192, L.EPI_BIAS, "8k")]:
+        bench_gemm(M, N, K, L.TILE_PP_256x256, epi, name=name)
+        bench_gemm_fp8(M, N, K, epi, name=name)
