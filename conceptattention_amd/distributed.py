@@ -11,7 +11,6 @@ all_gather of the small (C,h,w) fp32 heat maps at the end.  Contract: the N-GPU 
 from __future__ import annotations
 
 import os
-from typing import Sequence
 
 import torch
 import torch.distributed as dist

@@ -24,9 +24,8 @@ concept attention reads [concept keys | image keys] as two row segments without 
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
-from typing import Iterable, Optional
+from typing import Optional
 
 import torch
 

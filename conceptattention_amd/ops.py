@@ -6,7 +6,6 @@ library for shapes/alignment (ValueError on a rejected argument, nothing is laun
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 from dataclasses import dataclass
 from typing import Optional, Sequence

@@ -6,7 +6,7 @@ difference between flux-schnell and flux-dev is ``guidance_embed`` (util.py:46 v
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field, replace
+from dataclasses import dataclass, replace
 
 
 @dataclass(frozen=True)

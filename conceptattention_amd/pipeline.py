@@ -13,15 +13,15 @@ from __future__ import annotations
 
 import zlib
 from dataclasses import dataclass
-from typing import Callable, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
 
 from . import sampling
-from .flux_dit import FluxWeights, HeatmapRequest, HipFluxDiT
+from .flux_dit import HeatmapRequest, HipFluxDiT
 from .heatmaps import compute_heatmaps_from_vectors
-from .params import T5_TOKENS, configs
+from .params import configs
 
 
 @dataclass

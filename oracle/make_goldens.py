@@ -148,7 +148,6 @@ def full_blocks(ref, out_dir):
     weights and inputs so the HIP bf16 path sees the *same* numbers)."""
     from conceptattention_amd.params import FluxParams
     from conceptattention_amd.weights import synthetic_state_dict
-    from oracle.flux_oracle import rope_cos_sin, make_img_ids
     from oracle.full_block_case import full_block_inputs
     p = FluxParams()
     H, NH = p.hidden_size, p.num_heads

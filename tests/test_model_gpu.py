@@ -4,9 +4,7 @@ Tolerance semantics (SURVEY.md §7 "hard parts"): the HIP path 
 with fp32 accumulation; the oracle is fp32 on the SAME bf16-representable weights and inputs.
 Heat maps (softmax over concepts, values in [0,1]) must agree to <= 1e-3 max-abs per block;
 activations to a few bf16 ulps of their magnitude."""
-import math
 
-import numpy as np
 import pytest
 import torch
 

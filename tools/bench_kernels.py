@@ -1,6 +1,5 @@
 """Micro-benchmarks of the individual gfx950 kernels at the Flux shapes (development aid;
 bench.py is the judged benchmark).  Prints TFLOP/s or GB/s per kernel on random data."""
-import math
 import sys
 import os
 

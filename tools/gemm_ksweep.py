@@ -5,7 +5,6 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
 
 from conceptattention_amd import _lib as L
 from tools.bench_kernels import bench_gemm
