@@ -286,7 +286,9 @@ def main():
                                    "(generate_image-equivalent call; random-init weights, synthetic latents/embeddings)",
                        "calls_per_step_per_gpu": 1, "heatmap_layers": layer_indices,
                        "tflop_per_call": flops_call / 1e12, "parallelism": f"replica x{world} (work items round-robin)",
-                       "streams_per_gpu": args.streams},
+                       "streams_per_gpu": args.streams,
+                       **({"fp8_scope": "qkv/proj/mlp/linear1/linear2 of all blocks except double blocks "
+                                        f"{layer_indices} (the heat-map layers stay bf16)"} if fp8 else {})},
             "calls_per_s": calls / elapsed,
             "outputs_finite_and_normalised": maps_ok,
             "roofline": roof,

@@ -153,14 +153,16 @@ class HipFluxDiT:
     FP8_LINEARS = ("img_attn.qkv", "txt_attn.qkv", "img_attn.proj", "txt_attn.proj", "img_mlp.0", "txt_mlp.0",
                    "img_mlp.2", "txt_mlp.2", "linear1", "linear2")
 
-    def set_precision(self, precision: str):
+    def set_precision(self, precision: str, keep_bf16_layers=()):
         """"bf16" (default; the parity path) or "fp8": the six large projections of every block run on e4m3
         operands (weights quantised once per output channel, activations per token by the producing
-        kernel), accumulation fp32, everything else unchanged.  See DESIGN.md "fp8 mode" for the measured
-        heat-map deviation from the bf16 path."""
+        kernel), accumulation fp32, everything else unchanged.  ``keep_bf16_layers``: double blocks that stay
+        in bf16 even in fp8 mode (e.g. the layers whose attention outputs are turned into heat maps).  See
+        DESIGN.md "fp8 mode" for the measured heat-map deviation from the bf16 path."""
         if precision not in ("bf16", "fp8"):
             raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
         self.precision = precision
+        self.keep_bf16_layers = frozenset(int(l) for l in keep_bf16_layers)
         return self
 
     def _fp8_weights(self):
@@ -404,7 +406,7 @@ class HipFluxDiT:
         b = f"double_blocks.{i}."
         im, tm = b + "img_mod.lin", b + "txt_mod.lin"
         capture = return_vectors or (heatmaps is not None and i in heatmaps.layer_indices)
-        fp8 = self.precision == "fp8"
+        fp8 = self.precision == "fp8" and i not in self.keep_bf16_layers
         if fp8:
             XM8, XMS, ATT8, ATTS, HID8, HIDS = self.XM8, self.XMS, self.ATT8, self.ATTS, self.HID8, self.HIDS
             xm_out = dict(out=XM8, out_scale=XMS)

@@ -30,9 +30,9 @@ for seed in (1000, 1001):
     inp = synthetic_inputs(p, size, size, T, C, seed=seed, device="cpu", dtype=torch.bfloat16)
     x = {k: inp[k].to(dev) for k in ("latent", "txt", "vec", "concepts")}
     out = {}
-    for prec in ("bf16", "fp8"):
+    for prec in ("bf16", "fp8", "fp8_keep15_18"):
         for m in pipe._replicas:
-            m.set_precision(prec)
+            m.set_precision(prec.split("_")[0], keep_bf16_layers=range(15, 19) if "keep" in prec else ())
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         img, hm, cm = pipe.generate_on_device(x["latent"], x["txt"], x["vec"], x["concepts"],
@@ -42,18 +42,20 @@ for seed in (1000, 1001):
                                                      seed=seed)
         out[prec] = dict(img=img.float().cpu(), hm=hm[0].cpu(), cm=cm[0].cpu(), tab=tab[0].cpu(), ctab=ctab[0].cpu(),
                          sec=time.perf_counter() - t0)
-    a, b = out["bf16"], out["fp8"]
-    item = {"seed": seed}
-    for k, label in (("hm", "output_space_heatmaps"), ("cm", "cross_attention_maps")):
-        d = (a[k] - b[k]).abs()
-        item[label] = {"max_abs": d.max().item(), "mean_abs": d.mean().item(),
-                       "argmax_changed_frac": (a[k].argmax(0) != b[k].argmax(0)).float().mean().item(),
-                       "value_range": [a[k].min().item(), a[k].max().item()]}
-    d = (a["tab"] - b["tab"]).abs()   # [19 layers, C, side, side]
-    item["per_layer_single_forward_max_abs"] = [round(v, 5) for v in d.amax(dim=(1, 2, 3)).tolist()]
-    item["latent_rel_rms"] = ((a["img"] - b["img"]).norm() / a["img"].norm()).item()
-    item["seconds"] = {"bf16": a["sec"], "fp8": b["sec"]}
-    res["items"].append(item)
-    print(json.dumps(item), flush=True)
+    a = out["bf16"]
+    for mode in ("fp8", "fp8_keep15_18"):
+        b = out[mode]
+        item = {"seed": seed, "mode": mode}
+        for k, label in (("hm", "output_space_heatmaps"), ("cm", "cross_attention_maps")):
+            d = (a[k] - b[k]).abs()
+            item[label] = {"max_abs": d.max().item(), "mean_abs": d.mean().item(),
+                           "argmax_changed_frac": (a[k].argmax(0) != b[k].argmax(0)).float().mean().item(),
+                           "value_range": [a[k].min().item(), a[k].max().item()]}
+        d = (a["tab"] - b["tab"]).abs()   # [19 layers, C, side, side]
+        item["per_layer_single_forward_max_abs"] = [round(v, 5) for v in d.amax(dim=(1, 2, 3)).tolist()]
+        item["latent_rel_rms"] = ((a["img"] - b["img"]).norm() / a["img"].norm()).item()
+        item["seconds"] = {"bf16": a["sec"], mode: b["sec"]}
+        res["items"].append(item)
+        print(json.dumps(item), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "fp8_study.json"), "w"), indent=1)
