@@ -627,8 +627,9 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   } else {
     L.blocks_p1 = 8 * hx * L.nqb[1];
   }
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device: the attribute is per device
+  const unsigned long long dev_bit = ca_device_bit();
+  if (!(attr_done & dev_bit)) {
     hipError_t e = hipFuncSetAttribute((const void *)ca_attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        ATTN_LDS);
     if (e == hipSuccess)
@@ -639,7 +640,7 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
       ca_set_error("ca_attn_fwd_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done |= dev_bit;  // idempotent; a race only repeats the call
   }
   if (use_pp)
     hipLaunchKernelGGL(ca_attn_pp_kernel, dim3(total), dim3(512), ATTN_PP_LDS, (hipStream_t)stream, L);

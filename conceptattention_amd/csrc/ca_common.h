@@ -64,5 +64,12 @@ __device__ __forceinline__ float ca_silu(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950409f * x));
 }
 
+// bit of the calling thread's current device, for "done once per device" flags (hipFuncSetAttribute is per device)
+inline unsigned long long ca_device_bit() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return 1ull << (dev & 63);
+}
+
 // host-side error plumbing (ca_api.cpp)
 void ca_set_error(const char *fmt, ...);

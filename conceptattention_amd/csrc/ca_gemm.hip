@@ -690,15 +690,16 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
 template <int NL, int NHI, bool FP8 = false>
 int launch_pp(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
   using C = PPCfg<NL, NHI>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device: the attribute is per device
+  const unsigned long long dev_bit = ca_device_bit();
+  if (!(attr_done & dev_bit)) {
     hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_pp_kernel<NL, NHI, FP8>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
       ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done |= dev_bit;  // idempotent; a race only repeats the call
   }
   hipLaunchKernelGGL((ca_gemm_pp_kernel<NL, NHI, FP8>), dim3(total_tiles), dim3(512), C::LDS_BYTES, stream, L);
   hipError_t e = hipGetLastError();
@@ -712,15 +713,16 @@ int launch_pp(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
 template <int M_REP, int N_REP>
 int launch(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
   using C = Cfg<M_REP, N_REP>;
-  static bool attr_done = false;  // idempotent; a race only repeats the call
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device: the attribute is per device
+  const unsigned long long dev_bit = ca_device_bit();
+  if (!(attr_done & dev_bit)) {
     hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_kernel<M_REP, N_REP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
       ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done |= dev_bit;  // idempotent; a race only repeats the call
   }
   hipLaunchKernelGGL((ca_gemm_kernel<M_REP, N_REP>), dim3(total_tiles), dim3(512), C::LDS_BYTES, stream, L);
   hipError_t e = hipGetLastError();

@@ -498,8 +498,9 @@ extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void 
   hipLaunchKernelGGL(ca_gemv_kernel<NV>, dim3(grid), dim3(256), lds, s, x, ldx, (const bf16 *)W, (const bf16 *)bias, \
                      out, ldo, N, K, silu_input, accumulate)
   if (lds > 64 * 1024) {  // 5..8 vectors of K > 2048: opt in to the large dynamic-LDS carve-out once
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;  // one bit per device: the attribute is per device
+    const unsigned long long dev_bit = ca_device_bit();
+    if (!(attr_done & dev_bit)) {
       hipError_t e = hipSuccess;
       const void *fns[] = {(const void *)ca_gemv_kernel<5>, (const void *)ca_gemv_kernel<6>,
                            (const void *)ca_gemv_kernel<7>, (const void *)ca_gemv_kernel<8>};
@@ -509,7 +510,7 @@ extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void 
         ca_set_error("ca_gemv_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return CA_ERR_LAUNCH;
       }
-      attr_done = true;
+      attr_done |= dev_bit;  // idempotent; a race only repeats the call
     }
   }
   switch (nv) {

@@ -34,6 +34,18 @@ from . import ops
 from .params import FluxParams
 from .weights import iter_synthetic_state_dict, state_dict_spec
 
+def on_own_device(fn):
+    """Run a method with ``self.device`` as the current HIP device: the kernels launch on the calling thread's
+    current device and stream, so an object built for cuda:1 must not depend on the caller's current device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 DICT_KEYS = (
     "output_space_concept_vectors",
     "output_space_image_vectors",
@@ -264,6 +276,7 @@ class HipFluxDiT:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
+    @on_own_device
     def __call__(self, img, img_ids, txt, txt_ids, concepts, concept_ids, concept_vec, timesteps, y,
                  guidance=None, stop_after_multimodal_attentions: bool = False, edit_metadata=None,
                  iteration=None, joint_attention_kwargs=None, return_vectors: bool = True,
@@ -342,6 +355,7 @@ class HipFluxDiT:
                  silu_input=True, accumulate=True)
         self._modulations()
 
+    @on_own_device
     def precompute_conditioning(self, timesteps, y, concept_vec, guidance=None):
         """Conditioning vectors and every block's adaLN modulation for ALL diffusion steps up front
         (they depend only on (t, guidance, y), never on the activations): the 6.4 GB of modulation

@@ -17,7 +17,7 @@ import time
 import torch
 
 from . import sampling
-from .flux_dit import HipFluxDiT
+from .flux_dit import HipFluxDiT, on_own_device
 from .params import T5_TOKENS, configs
 
 
@@ -81,6 +81,7 @@ class FluxGenerator:
         return PIL.Image.fromarray((127.5 * (img + 1.0)).cpu().byte().numpy())
 
     @torch.no_grad()  # (the reference uses inference_mode; the resident workspace is reused across calls)
+    @on_own_device
     def generate_image(self, width, height, num_steps, guidance, seed, prompt, concepts, init_image=None,
                        image2image_strength=0.0, add_sampling_metadata=True, restrict_clip_guidance=False,
                        joint_attention_kwargs=None, latent=None):

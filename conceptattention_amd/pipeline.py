@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import sampling
-from .flux_dit import HeatmapRequest, HipFluxDiT
+from .flux_dit import HeatmapRequest, HipFluxDiT, on_own_device
 from .heatmaps import compute_heatmaps_from_vectors
 from .params import configs
 
@@ -112,6 +112,7 @@ class ConceptAttentionFluxPipeline:
 
     # ------------------------------------------------------------------ generate_image (:115-202)
     @torch.no_grad()
+    @on_own_device
     def generate_image(self, prompt: str, concepts: list, width: int = 1024, height: int = 1024,
                        return_cross_attention=False, layer_indices=list(range(15, 19)),
                        return_pil_heatmaps=True, seed: int = 0, num_inference_steps: int = 4,
@@ -136,6 +137,7 @@ class ConceptAttentionFluxPipeline:
         return self._finish(image, concept_heatmaps, cross_attention_maps, return_pil_heatmaps, cmap)
 
     @torch.no_grad()
+    @on_own_device
     def generate_many_on_device(self, items, n_streams: int = 2, **kw):
         """Throughput mode: independent work items (dicts with latent/txt/vec/concepts) are kept
         ``n_streams`` at a time in flight on separate HIP streams of this GPU, each with its own
@@ -180,6 +182,7 @@ class ConceptAttentionFluxPipeline:
         return results
 
     @torch.no_grad()
+    @on_own_device
     def generate_on_device(self, latent, txt, vec, concept_embeddings, layer_indices=list(range(15, 19)),
                            num_inference_steps: int = 4, guidance: float = 0.0, timesteps=None, fused: bool = True):
         gen = self._generate_steps(self.model, latent, txt, vec, concept_embeddings, layer_indices,
@@ -237,6 +240,7 @@ class ConceptAttentionFluxPipeline:
 
     # ------------------------------------------------------------------ per-layer x per-noise-level tables
     @torch.no_grad()
+    @on_own_device
     def layer_noise_sweep_on_device(self, latent, txt, vec, concept_embeddings, noise_levels, num_steps: int = 50,
                                     layer_indices=None, seed: int = 0, num_samples: int = 1,
                                     rank: int = 0, world: int = 1):
@@ -278,6 +282,7 @@ class ConceptAttentionFluxPipeline:
 
     # ------------------------------------------------------------------ encode_image (:204-357)
     @torch.no_grad()
+    @on_own_device
     def encode_image(self, image, concepts: list, prompt: str = "", width: int = 1024, height: int = 1024,
                      layer_indices=list(range(15, 19)), num_samples: int = 1, num_steps: int = 4,
                      noise_timestep: int = 2, device: str = "cuda:0", return_pil_heatmaps: bool = True,
