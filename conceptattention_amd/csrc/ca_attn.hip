@@ -19,6 +19,8 @@
 // Replaces F.scaled_dot_product_attention of the reference (see include/conceptattn.h).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ca_common.h"
 
 namespace {
@@ -63,6 +65,7 @@ __device__ unsigned long long ca_attn_dbg[32];
 #endif
 
 constexpr int KV_TILE = 64;
+constexpr float RESCALE_LOG2 = 8.0f;  // deferred-rescale threshold of the online softmax, in log2 units
 constexpr int TILE_BYTES = KV_TILE * 256;  // one K or V tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;
 constexpr int ATTN_LDS = 2 * BUF_BYTES;
@@ -125,8 +128,31 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
   const bf16 *v0p = (const bf16 *)P.v0 + head * 128;
   const bf16 *k1p = (const bf16 *)P.k1 + head * 128;
   const bf16 *v1p = (const bf16 *)P.v1 + head * 128;
+  // Lane constants of the copies: piece q = wave*(16/NW)+j covers key rows 4q..4q+3 of the tile; byte offset of
+  // this lane's 16 bytes inside a tile whose first row is at offset 0 (row r, swizzled chunk).
+  uint32_t koff[16 / NW], voff[16 / NW];
+#pragma unroll
+  for (int j = 0; j < 16 / NW; ++j) {
+    const int r = 4 * (wave * (16 / NW) + j) + st_row;
+    koff[j] = ((uint32_t)r * (uint32_t)ldkv + ((st_cp ^ (r & 15)) << 3)) * 2u;
+    voff[j] = ((uint32_t)r * (uint32_t)ldkv + ((st_cp ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 3)) * 2u;
+  }
   auto stage_tile = [&](int tile, int buf) {
     char *kb = smem + buf * BUF_BYTES;
+    const int lo = tile * KV_TILE;
+    // fast path (wave-uniform): all 64 rows exist and lie in one segment -> scalar tile base + lane constant
+    const bool in0 = lo + KV_TILE <= n0, in1 = lo >= n0 && lo + KV_TILE <= nkeys;
+    if (in0 || in1) {
+      const size_t ro = (size_t)(in0 ? lo : lo - n0) * ldkv;
+      const bf16 *kt = (in0 ? k0p : k1p) + ro, *vt = (in0 ? v0p : v1p) + ro;
+#pragma unroll
+      for (int j = 0; j < 16 / NW; ++j) {
+        const int q = wave * (16 / NW) + j;
+        ca_glds16_asm_s(kt, koff[j], kb + q * 1024);
+        ca_glds16_asm_s(vt, voff[j], kb + TILE_BYTES + q * 1024);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 16 / NW; ++j) {
       const int q = wave * (16 / NW) + j;
@@ -168,86 +194,95 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) stage_tile(t + 1, cur ^ 1);
-    if (active) {
-      const char *kbuf = smem + cur * BUF_BYTES;
-      const char *vbuf = kbuf + TILE_BYTES;
-      // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
-      f32x16 s[2];
+  // One K/V tile for this wave's 32 query rows.  MASKED is the ragged last tile only: kept out of the main
+  // loop's code (hipcc otherwise turns the uniform test into 32 v_cndmask per tile for every tile).
+  auto tile_body = [&](int t, int cur, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const char *kbuf = smem + cur * BUF_BYTES;
+    const char *vbuf = kbuf + TILE_BYTES;
+    // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
+    f32x16 s[2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const bf16x8 kf = *(const bf16x8 *)(kbuf + kb * 8192 + (k_lane ^ (ks << 5)));
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-        }
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 kf = *(const bf16x8 *)(kbuf + kb * 8192 + (k_lane ^ (ks << 5)));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
       }
-      // ---- mask the ragged last tile: key = 64*t + 32*kb + (r&3) + 8*(r>>2) + 4*h
-      if (t == nt - 1 && (nkeys & (KV_TILE - 1))) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = t * KV_TILE + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (key >= nkeys) s[kb][r] = -INFINITY;
-          }
-      }
-      // ---- online softmax (this lane: query row ql, 32 of the tile's 64 keys; lane^32 has the rest)
-      float mx = s[0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
-      // rescale O^T only when some row's running maximum grows (exact: alpha == 1 otherwise);
-      // after the first few tiles this is rare, which removes 64 multiplies per tile
-      if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-      }
-      float rs = 0.f;
+    }
+    if constexpr (MASKED) {  // key = 64*t + 32*kb + (r&3) + 8*(r>>2) + 4*h
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_run));
-          s[kb][r] = p;
-          rs += p;
+          const int key = t * KV_TILE + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (key >= nkeys) s[kb][r] = -INFINITY;
         }
-      l_run += rs;
-      // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; P^T fragments straight from the S^T registers
+    }
+    // ---- online softmax (this lane: query row ql, 32 of the tile's 64 keys; lane^32 has the rest)
+    float mx = s[0][0];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int sk = 0; sk < 2; ++sk) {
-          const bf16x8 pf = pack8(s[kb], 8 * sk);
-          const char *vrow = vbuf + (32 * kb + 16 * sk) * 256;
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
+    // The reference maximum of a row is only raised (and O^T, l rescaled) when some row of the wave exceeds
+    // it by more than RESCALE_LOG2: until then p = exp2(s - m_run) is at most 2^RESCALE_LOG2 instead of 1,
+    // which fp32 sums and bf16 P fragments carry without loss, and O/l is unchanged.  After the first
+    // tiles this is rare: no 64 accumulator multiplies per tile.
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + RESCALE_LOG2) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4 *)(vrow + (v_lane[0] ^ (db << 6))));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4 *)(vrow + 8 * 256 + (v_lane[1] ^ (db << 6))));
-            const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
-          }
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_run));
+        s[kb][r] = p;
+        rs += p;
+      }
+    l_run += rs;
+    // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; P^T fragments straight from the S^T registers
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const bf16x8 pf = pack8(s[kb], 8 * sk);
+        const char *vrow = vbuf + (32 * kb + 16 * sk) * 256;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4 *)(vrow + (v_lane[0] ^ (db << 6))));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4 *)(vrow + 8 * 256 + (v_lane[1] ^ (db << 6))));
+          const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
         }
       }
     }
+  };
+
+  const bool ragged = (nkeys & (KV_TILE - 1)) != 0;
+  const int nt_full = ragged ? nt - 1 : nt;  // tiles the main loop handles (no key masking)
+  int cur = 0;
+  for (int t = 0; t < nt_full; ++t) {
+    if (t + 1 < nt) stage_tile(t + 1, cur ^ 1);
+    if (active) tile_body(t, cur, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed (this wave's pieces)
     __syncthreads();
     cur ^= 1;
   }
+  if (ragged && active) tile_body(nt - 1, cur, std::true_type{});
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ;  d = 32*db + (r&3) + 8*(r>>2) + 4*h
   if (active) {

@@ -42,6 +42,25 @@ __device__ __forceinline__ void ca_glds16_asm(const void *gsrc, void *lds_wave_b
       : "memory");
 }
 
+// Same, in the "scalar base + 32-bit lane offset" addressing form: no 64-bit vector add per copy when the lane
+// offsets are loop constants and only the (wave-uniform) base moves.
+__device__ __forceinline__ void ca_glds16_asm_s(const void *sbase_uniform, uint32_t lane_byte_off, void *lds_wave_base) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ca_lptr)lds_wave_base);
+  const uint64_t b = (uint64_t)(uintptr_t)sbase_uniform;
+  const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const uint64_t base = ((uint64_t)bhi << 32) | blo;
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_byte_off), "s"(base), "s"(dst)
+      : "memory");
+}
+
 __device__ __forceinline__ float ca_bf2f(bf16 x) { return (float)x; }
 
 // pack two floats into one dword of 2 x bf16 (RNE; hipcc emits v_cvt_pk_bf16_f32)

@@ -203,7 +203,10 @@ def test_attention_two_segments_and_two_problems():
     kc, vc = torch.cat((k[:C], k[C + T:])), torch.cat((v[:C], v[C + T:]))
     close(out[:C], attn_ref(q[:C], kc, vc, nh), atol=1e-2)
     assert torch.equal(out32.bfloat16(), out[:C])  # the fp32 copy rounds to the bf16 output
-    assert (out32 - attn_ref(q[:C], kc, vc, nh)).abs().max() < 3e-3  # only P's bf16 rounding left
+    # only P's bf16 rounding is left in the fp32 copy: relative 2^-9 of |O| (<= 3 here).  With the deferred
+    # rescale a row's dominant weight is no longer exactly 1.0, so these peaky rows (inputs scaled by 1.5)
+    # see that bound in full; at the model's own statistics the rows agree to 2.6e-4 (test_model_gpu.py)
+    assert (out32 - attn_ref(q[:C], kc, vc, nh)).abs().max() < 8e-3
 
 
 def test_attention_online_softmax_rescale_spike():

@@ -194,6 +194,9 @@ def test_full_size_double_block_vs_reference_golden(golden):
     assert maxabs(m.LOGITS[:C], ref_lo) < 2e-2 * max(1.0, ref_lo.abs().max().item())
     # heat maps: <= 1e-3 max-abs (output space), the north-star tolerance
     hm = req.out_space.view(C, 64, 64)
+    print(f"\n[measured] full-size block: output-space heat map max-abs vs reference golden "
+          f"{maxabs(hm, g['heatmap_output_space'][0]):.3e}; concept attention rows "
+          f"{maxabs(m.ATT32[:C], g['concept_attn'][0]):.3e}")
     assert maxabs(hm, g["heatmap_output_space"][0]) < 1e-3
     assert abs(hm.sum(0) - 1).max().item() < 1e-5
     # cross-attention-space maps are ill-conditioned (logit std ~3 even with the scaled synthetic
