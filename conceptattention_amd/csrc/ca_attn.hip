@@ -196,8 +196,11 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 
   // One K/V tile for this wave's 32 query rows.  MASKED is the ragged last tile only: kept out of the main
   // loop's code (hipcc otherwise turns the uniform test into 32 v_cndmask per tile for every tile).
-  auto tile_body = [&](int t, int cur, auto masked_tag) {
+  // The LDS buffer index is a compile-time constant (tile t lives in buffer t & 1, the loop is unrolled by two),
+  // so every fragment address is a loop-invariant lane register plus an instruction immediate.
+  auto tile_body = [&](int t, auto cur_tag, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr int cur = decltype(cur_tag)::value;
     const char *kbuf = smem + cur * BUF_BYTES;
     const char *vbuf = kbuf + TILE_BYTES;
     // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
@@ -274,15 +277,25 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 
   const bool ragged = (nkeys & (KV_TILE - 1)) != 0;
   const int nt_full = ragged ? nt - 1 : nt;  // tiles the main loop handles (no key masking)
-  int cur = 0;
-  for (int t = 0; t < nt_full; ++t) {
+  auto iteration = [&](int t, auto cur_tag) {
+    constexpr int cur = decltype(cur_tag)::value;
     if (t + 1 < nt) stage_tile(t + 1, cur ^ 1);
-    if (active) tile_body(t, cur, std::false_type{});
+    if (active) tile_body(t, cur_tag, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed (this wave's pieces)
     __syncthreads();
-    cur ^= 1;
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  int t = 0;
+  for (; t + 1 < nt_full; t += 2) {
+    iteration(t, B0{});
+    iteration(t + 1, B1{});
   }
-  if (ragged && active) tile_body(nt - 1, cur, std::true_type{});
+  if (t < nt_full) iteration(t, B0{});
+  if (ragged && active) {
+    if ((nt - 1) & 1) tile_body(nt - 1, B1{}, std::true_type{});
+    else tile_body(nt - 1, B0{}, std::true_type{});
+  }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ;  d = 32*db + (r&3) + 8*(r>>2) + 4*h
   if (active) {
