@@ -85,6 +85,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own libamdhip64; whichever HIP runtime is mapped first serves the whole process.  Import
+    # torch before the dlopen so that the tensors' runtime is also the one the kernels are launched through
+    # (the other order leaves this library on /opt/rocm's runtime, which then reports "no ROCm-capable device").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ConceptAttnError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
