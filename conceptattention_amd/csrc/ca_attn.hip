@@ -301,16 +301,29 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
   if (active) {
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
-    if (qrow0 + ql < nq) {
-      bf16 *op = (bf16 *)P.out + (size_t)(qrow0 + ql) * P.ldo + head * 128 + 4 * h;
+    // bf16 output.  A lane holds columns 8g+4h .. 8g+4h+3 of its row (8 bytes) for g = 0..3 of every 32-column
+    // block; one v_permlane32_swap per dword trades group g of the upper half-wave for group g+1 of the lower
+    // one, after which every lane owns 16 contiguous bytes: 8 dwordx4 stores per lane instead of 16 dwordx2
+    // (the store tail is issue-bound, not bandwidth-bound).  All lanes take part in the swaps; only the
+    // store is predicated on the row being valid.
+    {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      bf16 *op = (bf16 *)P.out + (size_t)min(qrow0 + ql, nq - 1) * P.ldo + head * 128 + 8 * h;
+      const bool row_ok = qrow0 + ql < nq;
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const uint2 v = make_uint2(ca_pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                                     ca_pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
-          *(uint2 *)(op + 32 * db + 8 * g) = v;
+        for (int g = 0; g < 4; g += 2) {
+          const uint32_t ax = ca_pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+          const uint32_t ay = ca_pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          const uint32_t bx = ca_pack2(o[db][4 * g + 4] * inv, o[db][4 * g + 5] * inv);
+          const uint32_t by = ca_pack2(o[db][4 * g + 6] * inv, o[db][4 * g + 7] * inv);
+          const u32x2 sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+          const u32x2 sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+          if (row_ok) *(uint4 *)(op + 32 * db + 8 * g) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
+    }
+    if (qrow0 + ql < nq) {
       if (P.out_f32) {
         float *fp = P.out_f32 + (size_t)(qrow0 + ql) * P.ldo32 + head * 128 + 4 * h;
 #pragma unroll
