@@ -16,6 +16,8 @@
 //  * several problems share one launch (image stream + text/concept stream of a double block),
 //    tile ids are remapped so that the 32 workgroups that share an XCD (same blockIdx % 8) work
 //    on an 8(M) x 4(N) patch of tiles and reuse each other's panels in that XCD's L2.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "ca_common.h"
@@ -27,6 +29,8 @@ struct GemmLaunch {
   int32_t ntiles[CA_GEMM_MAX_PROBLEMS];
   int32_t mt[CA_GEMM_MAX_PROBLEMS];
   int32_t nt[CA_GEMM_MAX_PROBLEMS];
+  int32_t persist_tiles;  // ping-pong kernel: 0 = one workgroup per tile; else total tiles, walked by a CU-sized grid
+  int32_t persist_tiles_grid;  // host only: workgroups of the persistent grid (= CUs, a multiple of 8)
 };
 
 template <int M_REP, int N_REP>
@@ -313,20 +317,17 @@ __device__ __forceinline__ void ca_wait_vmcnt() {
 // tools/micro/mfma_fp8_probe.hip).  Same staging, barriers and wait counts; half the MFMA instructions, each
 // twice as long, so a K tile costs the same cycles and carries twice the FLOPs.  Row scales of A and W
 // (per-token / per-output-channel absmax quantisation) multiply the accumulators before the epilogue.
-template <int NL, int NHI, bool FP8 = false>
-__global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) {
+template <int NL, int NHI, bool FP8>
+__device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem, const int bid, const int nblk) {
   using C = PPCfg<NL, NHI>;
   constexpr int NT_ = NL + NHI;
   constexpr uint32_t ES = FP8 ? 1u : 2u;  // bytes per operand element
-  extern __shared__ __attribute__((aligned(128))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   CA_GSTAMP(0);
 
-  const int nblk = gridDim.x;
-  const int bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
   int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int prob = (lid >= L.ntiles[0]) ? 1 : 0;
@@ -687,6 +688,23 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
 #endif
 }
 
+// One workgroup per tile, or (persist_tiles > 0) a grid of one workgroup per CU walking the tiles with a stride of
+// the grid size: tile v keeps the XCD class of its workgroup (grid % 8 == 0), the next tile's prologue DMA
+// is issued while the previous tile's stores are still draining, and there is no workgroup dispatch between
+// rounds.  The barrier between tiles protects the QK-norm partial sums, which live in the first tile buffer.
+template <int NL, int NHI, bool FP8 = false>
+__global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) {
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  if (L.persist_tiles > 0) {
+    for (int v = blockIdx.x; v < L.persist_tiles; v += gridDim.x) {
+      ca_gemm_pp_tile<NL, NHI, FP8>(L, smem, v, L.persist_tiles);
+      __syncthreads();
+    }
+  } else {
+    ca_gemm_pp_tile<NL, NHI, FP8>(L, smem, blockIdx.x, gridDim.x);
+  }
+}
+
 template <int NL, int NHI, bool FP8 = false>
 int launch_pp(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
   using C = PPCfg<NL, NHI>;
@@ -701,7 +719,8 @@ int launch_pp(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
     }
     attr_done |= dev_bit;  // idempotent; a race only repeats the call
   }
-  hipLaunchKernelGGL((ca_gemm_pp_kernel<NL, NHI, FP8>), dim3(total_tiles), dim3(512), C::LDS_BYTES, stream, L);
+  const int grid = L.persist_tiles > 0 ? min(total_tiles, L.persist_tiles_grid) : total_tiles;
+  hipLaunchKernelGGL((ca_gemm_pp_kernel<NL, NHI, FP8>), dim3(grid), dim3(512), C::LDS_BYTES, stream, L);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ca_set_error("ca_gemm_bf16: launch failed: %s", hipGetErrorString(e));
@@ -895,6 +914,21 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
     L.p[1] = L.p[0];
   }
   hipStream_t s = (hipStream_t)stream;
+  {  // persistent walk of the tiles when there is more than one round of them (CA_GEMM_PERSIST=0 disables)
+    static const int persist_env = [] {
+      const char *e = getenv("CA_GEMM_PERSIST");
+      return e ? atoi(e) : 1;
+    }();
+    static int cus[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int &n = cus[dev & 63];
+    if (n == 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
+    if (persist_env && n > 0 && n % 8 == 0 && total > n) {
+      L.persist_tiles = total;
+      L.persist_tiles_grid = n;
+    }
+  }
   if (fp8) return launch_pp<2, 2, true>(L, total, s);
   switch (tile) {
     case CA_TILE_PP_256x256: return launch_pp<2, 2>(L, total, s);
