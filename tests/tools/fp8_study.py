@@ -31,6 +31,7 @@ for seed in (1000, 1001):
     x = {k: inp[k].to(dev) for k in ("latent", "txt", "vec", "concepts")}
     out = {}
     for prec in ("bf16", "fp8", "fp8_keep15_18"):
+        pipe.fp8_keep_heatmap_layers = "keep" in prec   # else generate_on_device re-applies the default keep set
         for m in pipe._replicas:
             m.set_precision(prec.split("_")[0], keep_bf16_layers=range(15, 19) if "keep" in prec else ())
         torch.cuda.synchronize()
