@@ -33,48 +33,11 @@ struct AttnLaunch {
   float scale_log2;   // softmax scale * log2(e)
 };
 
-#ifdef CA_ATTN_STAMP
-// Diagnostic build only (tools/stamp_attn.sh): per-phase cycle sums of waves 0 and 4 of workgroup 0.
-__device__ unsigned long long ca_attn_dbg[32];
-#define CA_STAMP(VAR)                                                              \
-  __builtin_amdgcn_sched_barrier(0);                                               \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(VAR)::"memory");       \
-  __builtin_amdgcn_sched_barrier(0)
-#define CA_ACC(SLOT, T0, T1) dbg_acc[SLOT] += (T1) - (T0)
-#else
-#define CA_STAMP(VAR)
-#define CA_ACC(SLOT, T0, T1)
-#endif
-
-// priority policy of the ping-pong kernel: 0 none, 1 raise around every matrix phase, 2 static for group 1
-#ifndef CA_ATTN_PRIO_MODE
-#define CA_ATTN_PRIO_MODE 1
-#endif
-#if CA_ATTN_PRIO_MODE == 1
-#define CA_PRIO_HI() __builtin_amdgcn_s_setprio(1)
-#define CA_PRIO_LO() __builtin_amdgcn_s_setprio(0)
-#elif CA_ATTN_PRIO_MODE == 3  // matrix phase always outranks the partner's vector phase: g0 1/0, g1 2/1
-#define CA_PRIO_HI() if (grp) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1)
-#define CA_PRIO_LO() if (grp) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0)
-#elif CA_ATTN_PRIO_MODE == 4  // vector phase outranks the matrix phase
-#define CA_PRIO_HI() __builtin_amdgcn_s_setprio(0)
-#define CA_PRIO_LO() __builtin_amdgcn_s_setprio(2)
-#else
-#define CA_PRIO_HI()
-#define CA_PRIO_LO()
-#endif
-
 constexpr int KV_TILE = 64;
 constexpr float RESCALE_LOG2 = 8.0f;  // deferred-rescale threshold of the online softmax, in log2 units
 constexpr int TILE_BYTES = KV_TILE * 256;  // one K or V tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;
 constexpr int ATTN_LDS = 2 * BUF_BYTES;
-#ifndef CA_PP_WINDOW
-#define CA_PP_WINDOW 6
-#endif
-constexpr int PP_WINDOW = CA_PP_WINDOW;             // LDS operand prefetch distance (MFMA steps)
-constexpr int PP_RING = 3;                          // K and V ring depth of the ping-pong kernel
-constexpr int ATTN_PP_LDS = 2 * PP_RING * TILE_BYTES;
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16 &s, int base) {
   bf16x8 r;
@@ -337,300 +300,6 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
   }
 }
 
-// =============================================================================================
-// Ping-pong variant (default).  Same tiles, fragments and LDS images as above, but the 8 waves run
-// as two groups of 4 (one wave of each group per SIMD) that are kept one barrier apart:
-//     phase X(t): O^T += V(t-1)^T P(t-1)^T ; S^T = K(t) Q^T          (32 MFMAs + LDS reads)
-//     phase Y(t): online softmax of S^T -> P(t), rescale O^T          (VALU) + LDS staging
-// so on every SIMD one wave is in its matrix phase while the other one is in its vector phase
-// (the matrix and vector pipes run concurrently only across waves).  Group 0's threads stage every
-// K tile, group 1's every V tile: in Y(t) a group writes tile t+1 of its matrix (loaded one tile
-// earlier into registers) and issues the loads of tile t+2.  With the one-barrier lag this gives
-//     K(t+1): written in interval 2t+1, read in 2t+2 / 2t+3, its buffer last read in 2t-1
-//     V(t+1): written in interval 2t+2, read in 2t+4 / 2t+5, its buffer last read in 2t+1
-// (2-deep rings, one s_barrier per phase, writers wait lgkmcnt(0) before the barrier).
-__global__ __launch_bounds__(512, 2) void ca_attn_pp_kernel(const AttnLaunch L) {
-  extern __shared__ __attribute__((aligned(256))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;  // 0: stages K, 1: stages V
-
-  int bid = blockIdx.x;
-  const int prob = bid < L.blocks_p1 ? 1 : 0;
-  if (!prob) bid -= L.blocks_p1;
-  const int nqb = L.nqb[prob];
-  const int xg = bid & 7, idx = bid >> 3;
-  const int head = xg + 8 * (idx / nqb);
-  const int qb = idx % nqb;
-  if (head >= L.num_heads) return;
-  const ca_attn_problem &P = L.p[prob];
-  const int nq = P.nq, n0 = P.n0, nkeys = P.n0 + P.n1;
-  const int ldkv = P.ldkv;
-
-  const int h = lane >> 5;
-  const int ql = lane & 31;
-  const int qrow0 = qb * 256 + wave * 32;
-  const bool active = qrow0 < nq;
-  const int qrow = min(qrow0 + ql, nq - 1);
-
-  bf16x8 qf[8];
-  {
-    const bf16 *qp = (const bf16 *)P.q + (size_t)qrow * P.ldq + head * 128 + h * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8 *)(qp + ks * 16);
-  }
-
-  // ---- staging by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip): a group's 4 waves move
-  // one 64x128 tile of "their" matrix per K/V tile, 4 wave-instructions of 1 KiB (= 4 key rows) each.
-  // The LDS image is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk.
-  const int gw = wave & 3;
-  const int st_row = lane >> 4, st_cp = lane & 15;  // row within the 4-row piece, LDS chunk
-  const bf16 *src0 = (const bf16 *)(grp ? P.v0 : P.k0) + head * 128;
-  const bf16 *src1 = (const bf16 *)(grp ? P.v1 : P.k1) + head * 128;
-  auto stage_tile = [&](int tile) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = gw * 4 + j;              // 1-KiB piece of the tile
-      const int r = 4 * q + st_row;          // key row inside the tile
-      const int swz = grp ? (((r & 3) << 2) | ((r >> 2) & 3)) : (r & 15);
-      const int kk = min(tile * KV_TILE + r, nkeys - 1);
-      const bool s0 = kk < n0;
-      const bf16 *src = (s0 ? src0 : src1) + (size_t)(s0 ? kk : kk - n0) * ldkv + ((st_cp ^ swz) << 3);
-      ca_glds16_asm(src, smem + (grp ? PP_RING * TILE_BYTES : 0) + (tile % PP_RING) * TILE_BYTES + q * 1024);
-    }
-  };
-#define CA_ATTN_DMA_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
-  const int k_lane = ql * 256 + (((h ^ (ql & 15)) & 15) << 4);
-  const int qq = (lane & 15) >> 2;
-  const int c_lane = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
-  int v_lane[2];
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int x = (qq << 2) | ((2 * jj + h) & 3);
-    v_lane[jj] = (4 * h + qq) * 256 + (((c_lane ^ x) & 15) << 4) + 8 * (lane & 1);
-  }
-
-  f32x16 o[4], s[2];
-  bf16x8 pf[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const float sl2 = L.scale_log2;
-  const int nt = (nkeys + KV_TILE - 1) / KV_TILE;
-
-  // ---- matrix phase as ONE operand stream: step m < 16 is the PV product (kb = m>>3, sk = (m>>2)&1,
-  // d-block m&3, operand = V^T fragment by two transposed reads), step m >= 16 is the QK^T product
-  // (kb = (m-16)>>3, ks = (m-16)&7, operand = K fragment).  The fragment of step m+PP_WINDOW is requested
-  // right after the MFMA of step m is issued, so the matrix pipe does not wait on LDS latency; the
-  // first PP_WINDOW V fragments are requested at the end of the preceding vector phase.
-  constexpr int W = PP_WINDOW;  // operand fragments requested ahead of the MFMA that consumes them
-  bf16x8 fr[W];
-  auto frag = [&](int m, int tile_v, int tile_k) -> bf16x8 {
-    if (m < 16) {
-      const int kb = m >> 3, sk = (m >> 2) & 1, db = m & 3;
-      const char *vrow = smem + PP_RING * TILE_BYTES + (tile_v % PP_RING) * TILE_BYTES + (32 * kb + 16 * sk) * 256;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4 *)(vrow + (v_lane[0] ^ (db << 6))));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4 *)(vrow + 8 * 256 + (v_lane[1] ^ (db << 6))));
-      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    } else {
-      const int kb = (m - 16) >> 3, ks = (m - 16) & 7;
-      return *(const bf16x8 *)(smem + (tile_k % PP_RING) * TILE_BYTES + kb * 8192 + (k_lane ^ (ks << 5)));
-    }
-  };
-#ifdef CA_ATTN_NO_LDS_READS  // timing experiment only: operands stay whatever the registers hold
-#define CA_FRAG(M, TV, TK) fr[(M) % W]
-#else
-#define CA_FRAG(M, TV, TK) frag((M), (TV), (TK))
-#endif
-#define CA_ATTN_STREAM(M_BEGIN, M_END, TILE_V, TILE_K)                                              \
-  _Pragma("unroll") for (int m = (M_BEGIN); m < (M_END); ++m) {                                      \
-    const bf16x8 cur = fr[m % W];                                                                    \
-    if (m < 16) {                                                                                    \
-      o[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, pf[m >> 2], o[m & 3], 0, 0, 0);        \
-    } else {                                                                                         \
-      const int kb_ = (m - 16) >> 3, ks_ = (m - 16) & 7;                                             \
-      if (ks_ == 0)                                                                                  \
-        s[kb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                            \
-            cur, qf[0], (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
-      else                                                                                           \
-        s[kb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, qf[ks_], s[kb_], 0, 0, 0);             \
-    }                                                                                                \
-    if (m + W < (M_END)) fr[m % W] = CA_FRAG(m + W, (TILE_V), (TILE_K));                                \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-  }
-  auto softmax = [&](int t) {
-#ifdef CA_ATTN_NO_SOFTMAX  // timing experiment only: keep the data flow, drop the vector work
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int sk = 0; sk < 2; ++sk) pf[2 * kb + sk] = pack8(s[kb], 8 * sk);
-    l_run += s[0][0];
-    return;
-#endif
-    if (t == nt - 1 && (nkeys & (KV_TILE - 1))) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KV_TILE + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (key >= nkeys) s[kb][r] = -INFINITY;
-        }
-    }
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
-    // rescale only when some row's running maximum grows (exact: alpha == 1 otherwise)
-    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    }
-    float rs = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_run));
-        s[kb][r] = p;
-        rs += p;
-      }
-    l_run += rs;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int sk = 0; sk < 2; ++sk) pf[2 * kb + sk] = pack8(s[kb], 8 * sk);
-  };
-#define CA_ATTN_SYNC()                     \
-  __builtin_amdgcn_sched_barrier(0);       \
-  __builtin_amdgcn_s_barrier();            \
-  __builtin_amdgcn_sched_barrier(0)
-#define CA_ATTN_LDS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-  // ---- prologue: K(0) (group 0) and V(0) (group 1) land before the first barrier
-  stage_tile(0);
-  // vmcnt(0) through the BUILTIN (0x0F70 = vmcnt 0, expcnt/lgkmcnt untouched): besides retiring the DMA it
-  // tells hipcc's wait-count pass that the Q-fragment loads above have landed, so it inserts no
-  // vmcnt waits for them inside the tile loop (where they would drain the hand-counted DMA).
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  CA_ATTN_SYNC();
-  if (grp == 1) { CA_ATTN_SYNC(); }  // stagger: group 1 runs one barrier behind group 0
-#if CA_ATTN_PRIO_MODE == 2
-  if (grp == 1) __builtin_amdgcn_s_setprio(1);  // static: the younger half wins arbitration throughout
-#endif
-
-  // Staging schedule, identical for both groups on their own matrix (3-deep rings): tile t+1 is
-  // DMA-issued at the start of the group's X(t) and retired (vmcnt 0) at the end of its Y(t).
-  // In intervals between barriers (group 0: X(t) = 2t, Y(t) = 2t+1; group 1 one later):
-  //   K(t+1): in flight 2t .. 2t+1, first read 2t+2;   its buffer held K(t-2), last read 2t-3
-  //   V(t+1): in flight 2t+1 .. 2t+2, first read at the end of 2t+3 (fragment prefetch of group 0);
-  //           its buffer held V(t-2), last read (PV(t-2) in X(t-1)) in interval 2t-1
-  if (nt > 1) stage_tile(1);
-  if (active) {  // X(0): QK(0) only
-#pragma unroll
-    for (int m = 16; m < 16 + W; ++m) fr[m % W] = frag(m, 0, 0);
-    CA_PRIO_HI();
-    CA_ATTN_STREAM(16, 32, 0, 0)
-    CA_PRIO_LO();
-  }
-  CA_ATTN_SYNC();
-#ifdef CA_ATTN_STAMP
-  unsigned long long dbg_acc[6] = {0, 0, 0, 0, 0, 0}, ts0, ts1, ts2, ts3, ts4, ts5;
-#endif
-  for (int t = 0; t < nt - 1; ++t) {  // every tile that has a successor
-    // ---- Y(t): vector phase; request the first V(t) fragments of the next matrix phase
-    CA_STAMP(ts0);
-    if (active) {
-      softmax(t);
-#pragma unroll
-      for (int m = 0; m < W; ++m) fr[m] = frag(m, t, 0);
-    }
-    CA_STAMP(ts1);
-    CA_ATTN_DMA_DONE();
-    CA_ATTN_LDS_DONE();
-    CA_STAMP(ts2);
-    CA_ATTN_SYNC();
-    CA_STAMP(ts3);
-    // ---- X(t+1): matrix phase  PV(t) + QK(t+1)
-    if (t + 2 < nt) stage_tile(t + 2);
-    if (active) {
-      CA_PRIO_HI();
-      CA_ATTN_STREAM(0, 32, t, t + 1)
-      CA_PRIO_LO();
-    }
-    CA_STAMP(ts4);
-    CA_ATTN_SYNC();
-    CA_STAMP(ts5);
-    CA_ACC(0, ts0, ts1);  // Y compute
-    CA_ACC(1, ts1, ts2);  // Y retire waits
-    CA_ACC(2, ts2, ts3);  // barrier after Y
-    CA_ACC(3, ts3, ts4);  // X stream
-    CA_ACC(4, ts4, ts5);  // barrier after X
-  }
-#ifdef CA_ATTN_STAMP
-  if (blockIdx.x == 200 && lane == 0 && (wave == 0 || wave == 4)) {
-    for (int i = 0; i < 5; ++i) ca_attn_dbg[(wave ? 8 : 0) + i] = dbg_acc[i];
-    ca_attn_dbg[(wave ? 8 : 0) + 5] = nt - 1;
-  }
-#endif
-  {  // last tile (kept out of the loop so the accumulators never merge across two code paths)
-    const int t = nt - 1;
-    if (active) {
-      softmax(t);
-#pragma unroll
-      for (int m = 0; m < W; ++m) fr[m] = frag(m, t, 0);
-    }
-    CA_ATTN_LDS_DONE();
-    CA_ATTN_SYNC();
-    if (active) {
-      CA_PRIO_HI();
-      CA_ATTN_STREAM(0, 16, t, t)
-      CA_PRIO_LO();
-    }
-    CA_ATTN_SYNC();
-  }
-  if (grp == 0) { CA_ATTN_SYNC(); }
-  CA_ATTN_DMA_DONE();
-
-  if (active) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    if (qrow0 + ql < nq) {
-      bf16 *op = (bf16 *)P.out + (size_t)(qrow0 + ql) * P.ldo + head * 128 + 4 * h;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const uint2 v = make_uint2(ca_pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                                     ca_pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
-          *(uint2 *)(op + 32 * db + 8 * g) = v;
-        }
-      if (P.out_f32) {
-        float *fp = P.out_f32 + (size_t)(qrow0 + ql) * P.ldo32 + head * 128 + 4 * h;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *(f32x4 *)(fp + 32 * db + 8 * g) =
-                f32x4{o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
-      }
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
@@ -639,15 +308,14 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
     ca_set_error("ca_attn_fwd_bf16: n_problems=%d num_heads=%d", n_problems, num_heads);
     return CA_ERR_ARG;
   }
-  // Default: 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: 295 us for
-  // 4352x4352x24 heads on MI355X.  A/B aids (same numerics): CA_ATTN_WAVES=4 = two independent 128-row
-  // workgroups per CU (321 us), CA_ATTN_PP=1 = the two-group ping-pong schedule below (350 us).
-  // What bounds all three (tools/micro/coissue.hip, tools/stamp_attn.py): per 64-key tile a wave issues
-  // 32 MFMAs (1024 cycles) and ~180 vector instructions of softmax (~850 cycles), and a vector wave next
-  // to a saturated MFMA wave on the same SIMD runs at only ~47 % of its solo speed.
-  static const bool use_pp = getenv("CA_ATTN_PP") != nullptr;
+  // Default: 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: ~258 us for
+  // 4352x4352x24 heads on MI355X.  A/B aid (same numerics): CA_ATTN_WAVES=4 = 128-row workgroups.
+  // What bounds it (tools/micro/coissue.hip): per 64-key tile a wave issues 32 MFMAs (1024 cycles) and
+  // ~200 vector instructions of softmax, and a vector wave next to a saturated MFMA wave on the same SIMD
+  // runs at only ~47 % of its solo speed.  A two-group ping-pong schedule of the same tiles was slower
+  // (350 us) and is not kept.
   static const int nw = (getenv("CA_ATTN_WAVES") && atoi(getenv("CA_ATTN_WAVES")) == 4) ? 4 : 8;
-  const int qrows = use_pp ? 256 : nw * 32;
+  const int qrows = nw * 32;
   AttnLaunch L = {};
   L.num_heads = num_heads;
   L.scale_log2 = scale * 1.4426950408889634f;
@@ -695,17 +363,13 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
                                        ATTN_LDS);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)ca_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void *)ca_attn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_PP_LDS);
     if (e != hipSuccess) {
       ca_set_error("ca_attn_fwd_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
     attr_done |= dev_bit;  // idempotent; a race only repeats the call
   }
-  if (use_pp)
-    hipLaunchKernelGGL(ca_attn_pp_kernel, dim3(total), dim3(512), ATTN_PP_LDS, (hipStream_t)stream, L);
-  else if (nw == 8)
+  if (nw == 8)
     hipLaunchKernelGGL(ca_attn_kernel<8>, dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
   else
     hipLaunchKernelGGL(ca_attn_kernel<4>, dim3(total), dim3(256), ATTN_LDS, (hipStream_t)stream, L);
@@ -716,9 +380,3 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   }
   return CA_OK;
 }
-
-#ifdef CA_ATTN_STAMP
-extern "C" int ca_debug_read_attn(unsigned long long *out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_attn_dbg), sizeof(unsigned long long) * 32);
-}
-#endif
