@@ -1,8 +1,11 @@
-import sys, os
-sys.path.insert(0, "/root/repo")
+"""GEMV (modulation weight streaming) micro-benchmark: vectors per pass vs achieved TB/s (development aid)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+
 from conceptattention_amd import ops
-sys.path.insert(0, "/root/repo/tools")
 dev = "cuda"
 def timeit(fn, iters=5, warm=2):
     for _ in range(warm): fn()
