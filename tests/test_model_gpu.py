@@ -274,3 +274,31 @@ def test_tiny_model_fp8_mode_tracks_bf16():
     hb = compute_heatmaps_from_vectors(d_b["output_space_image_vectors"][None], d_b["output_space_concept_vectors"][None],
                                        layers, [0])
     assert (ha - hb).abs().max().item() < 3e-2
+
+
+def test_full_size_block_image_stream_ignores_the_concepts():
+    """Size-independent property of the reference's block at the full geometry: the concept stream only READS
+    the image keys/values (modified_double_stream_block.py:121-123,162-166), so the image and text rows
+    after the block must not change by one bit when the concept tokens change or their count does; and
+    permuting the concepts permutes their own outputs."""
+    outs = {}
+    _, base, _ = _full_block_model("double", C=4, seed=7)     # one set of image / text / vec values for all runs
+    for tag, C, pick in (("c4", 4, [0, 1, 2, 3]), ("c4_perm", 4, [2, 0, 3, 1]), ("c1", 1, [0])):
+        m, _, (L, T, C_) = _full_block_model("double", C=C, seed=7)
+        m.X[:C].copy_(base["concepts"][0][pick])
+        m.X[C:C + T].copy_(base["txt"][0])
+        m.X[C + T:].copy_(base["img"][0])
+        m.VEC[0].copy_(base["vec"][0])
+        m.VEC[1].copy_(base["concept_vec"][0])
+        m._modulations()
+        m._double_block(0, C, T, L, None, None, False, None)
+        torch.cuda.synchronize()
+        outs[tag] = (m.X[C:C + T].clone(), m.X[C + T:].clone(), m.X[:C].clone(), m.ATT32[:C].clone())
+    for tag in ("c4_perm", "c1"):
+        assert torch.equal(outs[tag][0], outs["c4"][0]), f"text rows changed ({tag})"
+        assert torch.equal(outs[tag][1], outs["c4"][1]), f"image rows changed ({tag})"
+    # concept i of the permuted run is concept perm[i] of the first run (summation order over the 4 concept
+    # keys differs, so equality is to fp32 / bf16 rounding, not bitwise)
+    perm = [2, 0, 3, 1]
+    assert maxabs(outs["c4_perm"][3], outs["c4"][3][perm]) < 1e-4
+    assert maxabs(outs["c4_perm"][2], outs["c4"][2][perm]) < 4e-2
