@@ -302,3 +302,28 @@ def test_full_size_block_image_stream_ignores_the_concepts():
     perm = [2, 0, 3, 1]
     assert maxabs(outs["c4_perm"][3], outs["c4"][3][perm]) < 1e-4
     assert maxabs(outs["c4_perm"][2], outs["c4"][2][perm]) < 4e-2
+
+
+def test_forward_is_hip_graph_capturable():
+    """Every entry point is stream-ordered and allocates nothing, so a whole forward can be captured into a
+    HIP graph and replayed; the replay reproduces the eager result bit for bit."""
+    p, sd, inp = tiny_case()
+    m = HipFluxDiT(p, DEV)
+    m.load_state_dict(sd)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    kw = dict(img=O.patchify(inp["latent"]).to(DEV), img_ids=d["img_ids"], txt=d["txt"], txt_ids=d["txt_ids"],
+              concepts=d["concepts"], concept_ids=d["concept_ids"], concept_vec=d["concept_vec"], y=d["vec"],
+              timesteps=torch.tensor([0.5], device=DEV), return_vectors=False)
+    eager = m(**kw)[0].clone()          # also warms up (workspace, LDS opt-in attributes)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m(**kw)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(**kw)[0]
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
