@@ -181,3 +181,28 @@ def test_segmentation_model_contract(pipe):
     sc.update(m, c, m.bool().numpy())                   # a mask scored against itself: every pixel correct
     r = sc.result()
     assert r["pixAcc"] == pytest.approx(1.0) and r["mIoU"] == pytest.approx(1.0) and 0.5 < r["mAP"] <= 1.0
+
+
+@pytest.mark.parametrize("size,n_txt,C", [(208, 5, 1), (400, 11, 6)])
+def test_odd_sizes_end_to_end_vs_oracle(size, n_txt, C):
+    """Ragged everything at once: 13x13 / 25x25 image tokens (no multiple of the 64-key attention tile or the 256-row
+    GEMM tile), odd text lengths, 1 and 6 concepts (6 = two passes of the 4-concept logits kernel); two
+    diffusion steps through the fused pipeline against the fp32 oracle."""
+    from conceptattention_amd.weights import synthetic_inputs, synthetic_state_dict
+    p = tiny_params()
+    sd = {k: v.bfloat16().float() for k, v in synthetic_state_dict(p, seed=4).items()}
+    inp = {k: (v.bfloat16().float() if v.is_floating_point() else v)
+           for k, v in synthetic_inputs(p, size, size, n_txt=n_txt, n_concepts=C, seed=6).items()}
+    pl = ConceptAttentionFluxPipeline("flux-schnell", device=DEV, weights=sd, params=p, n_text_tokens=n_txt)
+    img, hm, cm = pl.generate_on_device(inp["latent"].to(DEV), inp["txt"].to(DEV), inp["vec"].to(DEV),
+                                        inp["concepts"].to(DEV), layer_indices=[0, 1], num_inference_steps=2)
+    side = size // 16
+    assert hm.shape == (1, C, side, side)
+    ts = O.get_schedule(2, side * side, shift=False)
+    img_o, d = O.denoise(sd, p, O.patchify(inp["latent"]), inp["img_ids"], inp["txt"], inp["txt_ids"], inp["vec"],
+                         ts, 0.0, inp["concepts"], inp["concept_ids"], inp["concept_vec"])
+    hm_o = O.compute_heatmaps(d["output_space_image_vectors"], d["output_space_concept_vectors"], [0, 1], [0, 1])
+    cm_o = O.compute_heatmaps(d["cross_attention_image_vectors"], d["cross_attention_concept_vectors"], [0, 1], [0, 1])
+    assert (img.float().cpu() - img_o).abs().max() < 0.1
+    assert (hm.cpu() - hm_o).abs().max() < 5e-3     # two steps, not teacher-forced (smoke() uses the same bound)
+    assert (cm.cpu() - cm_o).abs().max() < 2e-2
