@@ -25,7 +25,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe(float *out, int iters, un
   const int lane_off = (lane & 15) * 128 + ((((lane >> 4) ^ ((lane & 15) >> 1)) & 7) << 4);
   const int wm = WAVES == 8 ? wave >> 2 : wave >> 1;
   const int wn = WAVES == 8 ? wave & 3 : wave & 1;
-  const int a_off = wm * 128 * 128 / (WAVES == 8 ? 2 : 1) * 0 + (wm * (MI * 16) % 256) * 128 + lane_off;
+  const int a_off = ((wm * (MI * 16)) % 256) * 128 + lane_off;
   const int w_off = 32768 + ((wn * (NJ * 16)) % 256) * 128 + lane_off;
   f32x4 acc[MI][NJ];
 #pragma unroll
