@@ -306,8 +306,18 @@ class ConceptAttentionFluxPipeline:
         else:
             raise ValueError("encode_image needs a latent tensor or an injected autoencoder")
         txt, vec, con, con_ids, con_vec = self._embed(prompt, concepts)
+        out_space, cross_space = self._encode_maps(self.model, latent, txt, vec, con, con_ids, con_vec, layer_indices,
+                                                   num_samples, num_steps, noise_timestep, seed,
+                                                   stop_after_multi_modal_attentions, joint_attention_kwargs)
+        return self._finish(image, out_space, cross_space, return_pil_heatmaps, cmap)
+
+    def _encode_maps(self, model, latent, txt, vec, con, con_ids, con_vec, layer_indices, num_samples, num_steps,
+                     noise_timestep, seed, stop_after_multi_modal_attentions=True, joint_attention_kwargs=None):
+        """Device core of encode_image: one forward per noise sample on ``model``; returns the two fp32 maps
+        [1, C, side, side]."""
         C = con.shape[1]
         n_patches = (latent.shape[-1] // 2) * (latent.shape[-2] // 2)
+        height, width = latent.shape[-2] * 8, latent.shape[-1] * 8
         # the reference indexes the stacked samples with the float schedule values
         # (concept_attention_pipeline.py:311, SURVEY.md §3.4), which selects sample 0 only unless
         # a value >= 1; here every sample contributes equally (identical at num_samples=1).
@@ -322,11 +332,45 @@ class ConceptAttentionFluxPipeline:
             x = (t * noise.float() + (1.0 - t) * latent.float()).to(torch.bfloat16)
             inp = sampling.prepare_from_embeddings(x, txt, vec)
             t_vec = torch.full((1,), schedule[noise_timestep], device=self.device)
-            self.model(img=inp["img"], img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
-                       concepts=con, concept_ids=con_ids, concept_vec=con_vec, y=con_vec, timesteps=t_vec,
-                       guidance=torch.zeros(1, device=self.device),
-                       stop_after_multimodal_attentions=stop_after_multi_modal_attentions,
-                       joint_attention_kwargs=joint_attention_kwargs, return_vectors=False, heatmaps=req)
+            model(img=inp["img"], img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
+                  concepts=con, concept_ids=con_ids, concept_vec=con_vec, y=con_vec, timesteps=t_vec,
+                  guidance=torch.zeros(1, device=self.device),
+                  stop_after_multimodal_attentions=stop_after_multi_modal_attentions,
+                  joint_attention_kwargs=joint_attention_kwargs, return_vectors=False, heatmaps=req)
         side = int(round(n_patches ** 0.5))
-        return self._finish(image, req.out_space.view(1, C, side, side), req.cross_space.view(1, C, side, side),
-                            return_pil_heatmaps, cmap)
+        return req.out_space.view(1, C, side, side), req.cross_space.view(1, C, side, side)
+
+    @torch.no_grad()
+    @on_own_device
+    def encode_many_on_device(self, items, n_streams: int = 2, layer_indices=list(range(15, 19)),
+                              num_samples: int = 1, num_steps: int = 4, noise_timestep: int = 2, seed: int = 0):
+        """Batch form of encode_image for independent images (the loop of
+        experiments/imagenet_segmentation/run_experiment.py:137; BASELINE.json configs[3]): ``items`` are dicts with
+        latent (1,16,h/8,w/8), txt (1,T,4096), vec (1,768), concepts (1,C,4096) already on the device; they are
+        dealt round-robin to ``n_streams`` HIP streams, each with its own activation set (the same throughput
+        mode as generate_many_on_device).  Returns [(heat [1,C,s,s], cross [1,C,s,s]), ...], identical to
+        encoding the items one by one."""
+        n_streams = max(1, min(n_streams, len(items)))
+        while len(self._replicas) < n_streams:
+            self._replicas.append(HipFluxDiT(self.params, self.device, weights=self.model.weights,
+                                             precision=self.model.precision)
+                                  .set_precision(self.model.precision, self.model.keep_bf16_layers))
+        while len(self._streams) < n_streams:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        cur = torch.cuda.current_stream(self.device)
+        for st in self._streams[:n_streams]:
+            st.wait_stream(cur)
+        results = []
+        for i, it in enumerate(items):
+            slot = i % n_streams
+            with torch.cuda.stream(self._streams[slot]):
+                latent = it["latent"].to(self.device, torch.bfloat16)
+                con, con_ids, con_vec = sampling.concept_inputs(it["concepts"], it["vec"])
+                results.append(self._encode_maps(self._replicas[slot], latent, it["txt"], it["vec"], con, con_ids,
+                                                 con_vec, layer_indices, num_samples, num_steps, noise_timestep, seed))
+        for st in self._streams[:n_streams]:
+            cur.wait_stream(st)
+        for pair in results:
+            for t in pair:
+                t.record_stream(cur)
+        return results

@@ -206,3 +206,20 @@ def test_odd_sizes_end_to_end_vs_oracle(size, n_txt, C):
     assert (img.float().cpu() - img_o).abs().max() < 0.1
     assert (hm.cpu() - hm_o).abs().max() < 5e-3     # two steps, not teacher-forced (smoke() uses the same bound)
     assert (cm.cpu() - cm_o).abs().max() < 2e-2
+
+
+def test_encode_many_equals_one_by_one(pipe):
+    """Image batches on two streams (configs[3] shape of work) give the maps of encode_image item by item."""
+    from conceptattention_amd.weights import synthetic_inputs
+    p = pipe.params
+    items = []
+    for j in range(3):
+        inp = synthetic_inputs(p, 256, 256, 8, 2, seed=20 + j, dtype=torch.bfloat16)
+        items.append({k: inp[k].to(DEV) for k in ("latent", "txt", "vec", "concepts")})
+    kw = dict(layer_indices=[0, 1], num_samples=2, num_steps=4, noise_timestep=2, seed=5)
+    many = pipe.encode_many_on_device(items, n_streams=2, **kw)
+    assert len(many) == 3 and many[0][0].shape == (1, 2, 16, 16)
+    for it, (hm, cm) in zip(items, many):
+        one = pipe.encode_many_on_device([it], n_streams=1, **kw)[0]
+        assert torch.equal(hm, one[0]) and torch.equal(cm, one[1])
+        assert (hm.sum(1) - 1).abs().max() < 1e-5
