@@ -1,0 +1,68 @@
+"""Race screen for the hand-synchronised kernels (LDS-DMA hand-offs behind counted waits and barriers): the same
+launches are repeated many times, on two streams at once so that neighbours and timing vary, and every result
+is compared bit for bit with the first one.  A protocol slip shows up as a rare differing tile."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from conceptattention_amd import _lib as L, ops
+from tools.bench_kernels import rnd
+
+dev = "cuda"
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+nh, C, n = 24, 4, 4352
+buf = rnd(C + n, 9216)
+q, k, v = buf[:, :3072], buf[:, 3072:6144], buf[:, 6144:]
+a0, a1 = rnd(4096, 3072), rnd(260, 3072)
+w0, w1, b0 = rnd(12288, 3072, scale=0.02), rnd(12288, 3072, scale=0.02), rnd(12288)
+al, wl = rnd(4352, 15360), rnd(3072, 15360, scale=0.02)
+gate = torch.randn(3072, device=dev)
+qa, sa = ops.quantize_rows_fp8(a0)
+qw, sw = ops.quantize_rows_fp8(w0)
+
+
+def attn():
+    o = torch.zeros(C + n, 3072, device=dev, dtype=torch.bfloat16)
+    ops.attention([ops.Attn(q[C:], o[C:], k[C:], v[C:]), ops.Attn(q[:C], o[:C], k[:C], v[:C], k[C + 256:], v[C + 256:])], nh)
+    return o
+
+
+def mlp0():
+    o0 = torch.empty(4096, 12288, device=dev, dtype=torch.bfloat16)
+    o1 = torch.empty(260, 12288, device=dev, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(a0, w0, b0, o0, L.EPI_GELU_TANH), ops.Gemm(a1, w1, b0, o1, L.EPI_GELU_TANH)], L.TILE_PP_256x256)
+    return torch.cat((o0, o1))
+
+
+def linear2():
+    x = torch.zeros(4352, 3072, device=dev, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(al, wl, None, x, L.EPI_GATE_RESIDUAL, resid=x, gate=gate)], L.TILE_PP_256x256)
+    return x
+
+
+def fp8():
+    o = torch.empty(4096, 12288, device=dev, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(qa, qw, b0, o, a_scale=sa, w_scale=sw)])
+    return o
+
+
+cases = {"attention": attn, "mlp0 (grouped, persistent)": mlp0, "linear2 (K=15360)": linear2, "fp8 gemm": fp8}
+first = {name: fn() for name, fn in cases.items()}
+torch.cuda.synchronize()
+bad = {name: 0 for name in cases}
+t0 = time.time()
+names = list(cases)
+for it in range(iters):
+    outs = []
+    for j, name in enumerate(names):
+        st = s1 if (it + j) % 2 == 0 else s2
+        with torch.cuda.stream(st):
+            outs.append((name, cases[name]()))
+    torch.cuda.synchronize()
+    for name, o in outs:
+        if not torch.equal(o, first[name]):
+            bad[name] += 1
+    if it % 50 == 49:
+        print(f"iteration {it + 1}: mismatches so far {bad} ({time.time() - t0:.0f} s)", flush=True)
+print("RESULT", "clean" if not any(bad.values()) else f"MISMATCHES {bad}")
+sys.exit(1 if any(bad.values()) else 0)
