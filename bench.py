@@ -87,6 +87,49 @@ def cpu_baseline(p, L, T, C, steps_per_call, n_layers_double, n_layers_single):
             "seconds_per_call": call_s}
 
 
+def stub_main(args):
+    """--stub-workload: the N-rank plumbing of this file (init, item sharding, barrier-bracketed timing, the
+    gather, max over ranks, rank 0's single JSON line) on CPU tensors; used by tests/test_bench_launcher_cpu.py."""
+    from conceptattention_amd import distributed as D
+    rank, world, _ = D.init_from_env()
+    C = args.concepts
+    n_timed = world * args.steps
+    mine = D.shard_items(n_timed, rank, world)
+    D.barrier()
+    t0 = time.perf_counter()
+    local = torch.stack([torch.full((2, C, 4, 4), float(j)) for j in mine])
+    allm = D.gather_heatmaps(local, n_timed, rank, world)
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, "cpu")
+    ok = all(bool((allm[j] == float(j)).all()) for j in range(n_timed))
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (launcher test, no GPU work)", "value": n_timed * C / max(elapsed, 1e-9),
+                          "unit": "stub-items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "gathered_in_item_order": ok,
+                          "data": "stub"}), flush=True)
+    D.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def self_launch(n_gpus: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` without an outer launcher: start one fresh process per GPU through
+    torch.distributed.run (rendezvous on 127.0.0.1) BEFORE this process has touched the GPU, let rank 0's JSON line
+    go straight to our stdout and return the children's exit code.  (One process per device is also how the
+    reference is used on several GPUs: experiments/imagenet_segmentation/run_experiment.py:56.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,7 +148,19 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-launch HIP-event timing of the GEMM kernel (roofline.achieved then "
                          "comes from whole-path FLOPs / wall time)")
+    ap.add_argument("--stub-workload", action="store_true",
+                    help="TEST ONLY: replace the GPU work of an item by a constant CPU tensor so that the launcher, "
+                         "sharding, gather and JSON plumbing can be exercised without a GPU (gloo); the line says so")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:  # before any rendezvous is attempted
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: run "
+                         f"`python bench.py --gpus {args.gpus}` (self-launching) or torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if args.stub_workload:
+        return stub_main(args)
 
     from conceptattention_amd import distributed as D
     from conceptattention_amd import ops
@@ -115,9 +170,6 @@ def main():
     from conceptattention_amd.weights import synthetic_inputs
 
     rank, world, local = D.init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
     # CA_BENCH_DEVICE pins every rank to one device (multi-process rehearsal on a 1-GPU box, with
     # CA_DIST_BACKEND=gloo since RCCL refuses two ranks on one GPU); normally rank r uses GPU LOCAL_RANK
     dev = torch.device(os.environ.get("CA_BENCH_DEVICE") or f"cuda:{local}")
@@ -274,7 +326,7 @@ def main():
                             "peak (attention and the small kernels stay bf16); frac is the e4m3 GEMM kernel "
                             "against the 5 PFLOP/s fp8 peak")
         res = {
-            "metric": "concept-heatmaps/sec (1024x1024, 4 concepts, 4 steps)",
+            "metric": f"concept-heatmaps/sec ({args.size}x{args.size}, {C} concepts, {args.diffusion_steps} steps)",
             "value": calls * C / elapsed,
             "unit": "concept-heatmaps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -15,6 +15,8 @@ CA_VERSION = 100
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU, EPI_QKV_NORM_ROPE = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_256x256, TILE_256x192, TILE_256x128, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_PP_256x256, TILE_PP_256x128, TILE_PP_256x192 = 5, 6, 7
+NORM_SOFTMAX, NORM_SPARSEMAX, NORM_ENTMAX15 = 0, 1, 2
+NORMS = {"softmax": NORM_SOFTMAX, "sparsemax": NORM_SPARSEMAX, "entmax15": NORM_ENTMAX15}
 MAX_SEGMENTS = 4
 GEMM_MAX_PROBLEMS = 2
 
@@ -68,6 +70,8 @@ SIGNATURES = {
                                          C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ca_heatmap_softmax_accumulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                                 C.c_void_p]),
+    "ca_heatmap_norm_accumulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                             C.c_void_p]),
     "ca_timestep_embedding_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float,
                                             C.c_void_p]),
     "ca_axpy_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),

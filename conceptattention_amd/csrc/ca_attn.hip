@@ -21,6 +21,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "ca_common.h"
 
 namespace {
@@ -356,9 +358,9 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   } else {
     L.blocks_p1 = 8 * hx * L.nqb[1];
   }
-  static unsigned long long attr_done = 0;  // one bit per device: the attribute is per device
+  static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
   const unsigned long long dev_bit = ca_device_bit();
-  if (!(attr_done & dev_bit)) {
+  if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute((const void *)ca_attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        ATTN_LDS);
     if (e == hipSuccess)
@@ -367,7 +369,7 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
       ca_set_error("ca_attn_fwd_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
-    attr_done |= dev_bit;  // idempotent; a race only repeats the call
+    attr_done.fetch_or(dev_bit, std::memory_order_release);  // idempotent: a race only repeats the call
   }
   if (nw == 8)
     hipLaunchKernelGGL(ca_attn_kernel<8>, dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);

@@ -20,6 +20,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "ca_common.h"
 
 namespace {
@@ -708,16 +710,16 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
 template <int NL, int NHI, bool FP8 = false>
 int launch_pp(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
   using C = PPCfg<NL, NHI>;
-  static unsigned long long attr_done = 0;  // one bit per device: the attribute is per device
+  static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
   const unsigned long long dev_bit = ca_device_bit();
-  if (!(attr_done & dev_bit)) {
+  if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_pp_kernel<NL, NHI, FP8>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
       ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
-    attr_done |= dev_bit;  // idempotent; a race only repeats the call
+    attr_done.fetch_or(dev_bit, std::memory_order_release);  // idempotent: a race only repeats the call
   }
   const int grid = L.persist_tiles > 0 ? min(total_tiles, L.persist_tiles_grid) : total_tiles;
   hipLaunchKernelGGL((ca_gemm_pp_kernel<NL, NHI, FP8>), dim3(grid), dim3(512), C::LDS_BYTES, stream, L);
@@ -732,16 +734,16 @@ int launch_pp(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
 template <int M_REP, int N_REP>
 int launch(const GemmLaunch &L, int total_tiles, hipStream_t stream) {
   using C = Cfg<M_REP, N_REP>;
-  static unsigned long long attr_done = 0;  // one bit per device: the attribute is per device
+  static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
   const unsigned long long dev_bit = ca_device_bit();
-  if (!(attr_done & dev_bit)) {
+  if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_kernel<M_REP, N_REP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
       ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
-    attr_done |= dev_bit;  // idempotent; a race only repeats the call
+    attr_done.fetch_or(dev_bit, std::memory_order_release);  // idempotent: a race only repeats the call
   }
   hipLaunchKernelGGL((ca_gemm_kernel<M_REP, N_REP>), dim3(total_tiles), dim3(512), C::LDS_BYTES, stream, L);
   hipError_t e = hipGetLastError();
@@ -919,11 +921,14 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
       const char *e = getenv("CA_GEMM_PERSIST");
       return e ? atoi(e) : 1;
     }();
-    static int cus[64] = {0};
+    static std::atomic<int> cus[64];  // CU count per device, 0 = not asked yet (a race only repeats the query)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int &n = cus[dev & 63];
-    if (n == 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
+    int n = cus[dev & 63].load(std::memory_order_relaxed);
+    if (n == 0) {
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
+      cus[dev & 63].store(n, std::memory_order_relaxed);
+    }
     if (persist_env && n > 0 && n % 8 == 0 && total > n) {
       L.persist_tiles = total;
       L.persist_tiles_grid = n;

@@ -2,6 +2,8 @@
 // QK-RMSNorm+RoPE, small-batch GEMV (weight streaming), concept heat-map reduction, Euler axpy.
 // All use 16-byte-per-lane coalesced accesses and fp32 arithmetic; none of them is shaped into
 // an MFMA product (they are bandwidth-bound: see DESIGN.md for bytes per unit).
+#include <atomic>
+
 #include "ca_common.h"
 
 namespace {
@@ -348,6 +350,74 @@ __global__ __launch_bounds__(256) void ca_heatmap_softmax_kernel(const float *__
   for (int c = 0; c < C; ++c) acc[(size_t)c * L + p] += __expf(logits[(size_t)c * L + p] - mx) * inv;
 }
 
+// acc[c,p] += weight * sparsemax_c / entmax15_c (logits[:,p]): the two sparse alternatives to the softmax over
+// concepts (concept_attention_pipeline.py:66-69 calls the third-party `entmax` package for them).  Both are the
+// published sort-and-threshold algorithms: sparsemax (Martins & Astudillo 2016, Alg. 1): z sorted descending,
+// k = max{j : 1 + j z_(j) > sum_{i<=j} z_(i)}, tau = (sum_{i<=k} z_(i) - 1) / k, p = max(z - tau, 0);
+// 1.5-entmax (Peters, Niculae & Martins 2019, Alg. 2): x = (z - max z) / 2 sorted, for every prefix j
+// mean M_j, ss_j = j (mean of squares - M_j^2), tau_j = M_j - sqrt(max((1 - ss_j) / j, 0)),
+// k = #{j : tau_j <= x_(j)}, p = max(x - tau_k, 0)^2.  One thread per patch, the C <= 16 logits in registers.
+template <int CMAX, bool ENTMAX15>
+__global__ __launch_bounds__(256) void ca_heatmap_sparse_kernel(const float *__restrict__ logits, int C, int L,
+                                                                float weight, float *__restrict__ acc) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= L) return;
+  float z[CMAX], srt[CMAX];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    z[c] = c < C ? logits[(size_t)c * L + p] : -INFINITY;
+    mx = fmaxf(mx, z[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    z[c] = (z[c] - mx) * (ENTMAX15 ? 0.5f : 1.0f);  // both maps are shift-invariant; -inf padding stays -inf
+    srt[c] = z[c];
+  }
+  // odd-even transposition sort, descending (fully unrolled: the array never leaves the registers)
+#pragma unroll
+  for (int pass = 0; pass < CMAX; ++pass)
+#pragma unroll
+    for (int i = pass & 1; i + 1 < CMAX; i += 2) {
+      const float a = srt[i], b = srt[i + 1];
+      srt[i] = fmaxf(a, b);
+      srt[i + 1] = fminf(a, b);
+    }
+  float tau = 0.f;
+  float cs = 0.f, cs2 = 0.f;
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j < CMAX; ++j) {
+    if (j < C) {
+      cs += srt[j];
+      cs2 += srt[j] * srt[j];
+      const float rho = (float)(j + 1);
+      float tj;
+      bool in;
+      if (ENTMAX15) {
+        const float mean = cs / rho;
+        const float ss = rho * (cs2 / rho - mean * mean);
+        tj = mean - sqrtf(fmaxf((1.0f - ss) / rho, 0.0f));
+        in = tj <= srt[j];
+      } else {
+        tj = (cs - 1.0f) / rho;
+        in = 1.0f + rho * srt[j] > cs;
+      }
+      if (in) {  // the support is a prefix of the sorted order, so the last j that passes is k
+        k = j + 1;
+        tau = tj;
+      }
+    }
+  }
+  (void)k;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < C) {
+      const float d = fmaxf(z[c] - tau, 0.f);
+      acc[(size_t)c * L + p] += weight * (ENTMAX15 ? d * d : d);
+    }
+}
+
 __global__ __launch_bounds__(256) void ca_axpy_kernel(bf16 *__restrict__ x, const bf16 *__restrict__ y, float a,
                                                       long n) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
@@ -498,9 +568,9 @@ extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void 
   hipLaunchKernelGGL(ca_gemv_kernel<NV>, dim3(grid), dim3(256), lds, s, x, ldx, (const bf16 *)W, (const bf16 *)bias, \
                      out, ldo, N, K, silu_input, accumulate)
   if (lds > 64 * 1024) {  // 5..8 vectors of K > 2048: opt in to the large dynamic-LDS carve-out once
-    static unsigned long long attr_done = 0;  // one bit per device: the attribute is per device
+    static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
     const unsigned long long dev_bit = ca_device_bit();
-    if (!(attr_done & dev_bit)) {
+    if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
       hipError_t e = hipSuccess;
       const void *fns[] = {(const void *)ca_gemv_kernel<5>, (const void *)ca_gemv_kernel<6>,
                            (const void *)ca_gemv_kernel<7>, (const void *)ca_gemv_kernel<8>};
@@ -510,7 +580,7 @@ extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void 
         ca_set_error("ca_gemv_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return CA_ERR_LAUNCH;
       }
-      attr_done |= dev_bit;  // idempotent; a race only repeats the call
+      attr_done.fetch_or(dev_bit, std::memory_order_release);  // idempotent: a race only repeats the call
     }
   }
   switch (nv) {
@@ -559,6 +629,25 @@ extern "C" int ca_heatmap_softmax_accumulate(const float *logits, int32_t C, int
   hipLaunchKernelGGL(ca_heatmap_softmax_kernel, dim3((L + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, C, L,
                      weight, acc);
   return check_launch("ca_heatmap_softmax_accumulate");
+}
+
+extern "C" int ca_heatmap_norm_accumulate(const float *logits, int32_t C, int32_t L, int32_t norm, float weight,
+                                          float *acc, ca_stream_t stream) {
+  if (norm == CA_NORM_SOFTMAX) return ca_heatmap_softmax_accumulate(logits, C, L, weight, acc, stream);
+  if (!logits || !acc || C < 1 || C > 16 || L < 1 || (norm != CA_NORM_SPARSEMAX && norm != CA_NORM_ENTMAX15)) {
+    ca_set_error("ca_heatmap_norm_accumulate: bad arguments (C=%d L=%d norm=%d; sparse norms need C <= 16)", C, L, norm);
+    return CA_ERR_ARG;
+  }
+  const dim3 grid((L + 255) / 256), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (norm == CA_NORM_SPARSEMAX) {
+    if (C <= 8) hipLaunchKernelGGL((ca_heatmap_sparse_kernel<8, false>), grid, block, 0, s, logits, C, L, weight, acc);
+    else hipLaunchKernelGGL((ca_heatmap_sparse_kernel<16, false>), grid, block, 0, s, logits, C, L, weight, acc);
+  } else {
+    if (C <= 8) hipLaunchKernelGGL((ca_heatmap_sparse_kernel<8, true>), grid, block, 0, s, logits, C, L, weight, acc);
+    else hipLaunchKernelGGL((ca_heatmap_sparse_kernel<16, true>), grid, block, 0, s, logits, C, L, weight, acc);
+  }
+  return check_launch("ca_heatmap_norm_accumulate");
 }
 
 extern "C" int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream) {

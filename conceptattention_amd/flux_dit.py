@@ -135,6 +135,7 @@ class HeatmapRequest:
     per_layer_out: Optional[torch.Tensor] = None
     per_layer_cross: Optional[torch.Tensor] = None
     per_layer_weight: float = 1.0
+    norm: int = L.NORM_SOFTMAX    # weighting across concepts: softmax | sparsemax | entmax15 (_lib.NORM_*)
 
 
 class HipFluxDiT:
@@ -183,6 +184,15 @@ class HipFluxDiT:
             W.fp8 = {name: ops.quantize_rows_fp8(t) for name, t in W.tensors.items()
                      if name.endswith(".weight") and name.rsplit(".", 1)[0].split(".", 2)[-1] in self.FP8_LINEARS}
         return W.fp8
+
+    def materialize(self):
+        """Build the lazily created state that model instances SHARE (the fp8 weight images live on the common
+        FluxWeights object) on the CURRENT stream.  Callers that are about to run replicas on other streams call
+        this first and then make those streams wait on the current one; otherwise a replica could launch an fp8
+        GEMM on weight images whose quantisation kernels are still queued on another stream."""
+        if self.precision == "fp8":
+            self._fp8_weights()
+        return self
 
     def _gemm(self, fp8, a, a8, a8s, wname, bias, out, *args, **kw):
         """One problem of a grouped launch in the current precision."""
@@ -247,14 +257,21 @@ class HipFluxDiT:
     def _rope_table(self, img_ids, txt_ids, concept_ids, C, T):
         """(cos, sin) per row in [concept | text | image] order.  rope(): angles in float64,
         stored fp32 (flux/math.py:15-22); EmbedND concatenates the axes (layers.py:18-25)."""
-        def ver(t):  # inference-mode tensors have no version counter
+        # The table is cached only for ids whose CONTENT is known: tensors made by sampling.make_img_ids /
+        # sampling.zero_ids carry a tag (what they hold + their version counter at creation).  A pointer/shape
+        # key is not content identity (the allocator re-uses addresses: 2048x512 then 512x2048 would hit), so
+        # untagged or since-modified ids rebuild the table on every forward (a few tiny kernels).
+        def tag(t):
+            g = getattr(t, "_ca_ids_tag", None)
+            if g is None:
+                return None
             try:
-                return t._version
-            except RuntimeError:
-                return -1
-        key = tuple((t.data_ptr(), ver(t), tuple(t.shape)) for t in (img_ids, txt_ids, concept_ids))
-        if any(k[1] < 0 for k in key):
-            key = None  # cannot prove the ids are unchanged: recompute
+                return g[0] if t._version == g[1] else None
+            except RuntimeError:  # inference-mode tensors have no version counter
+                return None
+        key = tuple(tag(t) for t in (img_ids, txt_ids, concept_ids))
+        if any(k is None for k in key):
+            key = None
         if key is not None and self._rope_key == key:
             return
         ids = torch.cat((concept_ids[0], txt_ids[0], img_ids[0]), 0).to(self.device, torch.float64)
@@ -530,9 +547,10 @@ class HipFluxDiT:
             for img_vec, con_vec, acc, table in ((ATT[CT:], self.ATT32[:C], heatmaps.out_space, heatmaps.per_layer_out),
                                                  (QPRE[CT:], QPRE[:C], heatmaps.cross_space, heatmaps.per_layer_cross)):
                 ops.heatmap_logits(img_vec, con_vec, self.LOGITS[:C])
-                ops.heatmap_softmax_accumulate(self.LOGITS[:C], acc, heatmaps.weight)
+                ops.heatmap_softmax_accumulate(self.LOGITS[:C], acc, heatmaps.weight, heatmaps.norm)
                 if table is not None:
-                    ops.heatmap_softmax_accumulate(self.LOGITS[:C], table[li], heatmaps.per_layer_weight)
+                    ops.heatmap_softmax_accumulate(self.LOGITS[:C], table[li], heatmaps.per_layer_weight,
+                                                   heatmaps.norm)
         if return_vectors:
             H = self.hidden_size
             out["output_space_concept_vectors"].append(ATT[:C].clone()[None])

@@ -2,7 +2,7 @@
 ``compute_heatmaps_from_vectors`` (concept_attention/concept_attention_pipeline.py:29-91).
 
 Semantics kept: optional head merge (:43-51), dot products over the feature axis (:57-61),
-softmax ACROSS concepts per patch (:64-65), select timesteps then layers (:76-77), mean (:78-82),
+softmax / sparsemax / entmax15 ACROSS concepts per patch (:64-71), select timesteps then layers (:76-77), mean (:78-82),
 reshape to the patch grid (:85-90).  Differences, both deliberate and documented in DESIGN.md:
 the (t, layer) pairs that are not selected are never computed (the reference computes all and
 slices), and products/softmax/mean are fp32 (the reference runs them in the activations' bf16).
@@ -14,7 +14,18 @@ import math
 
 import torch
 
+from . import _lib as L
 from . import ops
+
+
+def resolve_norm(softmax: bool, attention_norm: str) -> int:
+    """The reference's branch order (concept_attention_pipeline.py:64-71): softmax if ``softmax`` or
+    attention_norm == "softmax", else entmax15 / sparsemax, else ValueError."""
+    if softmax or attention_norm == "softmax":
+        return L.NORM_SOFTMAX
+    if attention_norm in ("entmax15", "sparsemax"):
+        return L.NORMS[attention_norm]
+    raise ValueError(f"Unknown attention_norm={attention_norm}")
 
 
 def linear_normalization(x: torch.Tensor, dim: int) -> torch.Tensor:
@@ -31,10 +42,9 @@ def compute_heatmaps_from_vectors(image_vectors, concept_vectors, layer_indices,
                                   attention_norm: str = "sparsemax"):
     """image_vectors [t, layers, 1, patches, dim] (or [t, layers, 1, heads, patches, 128]),
     concept_vectors likewise with concepts in place of patches -> fp32 [1, concepts, side, side]."""
-    if not (softmax or attention_norm == "softmax"):
-        # entmax15 / sparsemax come from the third-party `entmax` package, which the reference
-        # neither pins nor vendors (SURVEY.md §8c: parity unpinned) -> not offered.
-        raise NotImplementedError(f"attention_norm={attention_norm!r} with softmax=False is not supported")
+    # entmax15 / sparsemax: the reference calls the third-party `entmax` package, which it neither pins nor
+    # vendors; the kernels implement the published algorithms (parity with that package UNPINNED, SURVEY.md §8c)
+    norm = resolve_norm(softmax, attention_norm)
     if image_vectors.dim() == 6:
         t, l, b, h, n, d = image_vectors.shape
         image_vectors = image_vectors.permute(0, 1, 2, 4, 3, 5).reshape(t, l, b, n, h * d)
@@ -58,7 +68,7 @@ def compute_heatmaps_from_vectors(image_vectors, concept_vectors, layer_indices,
             iv = image_vectors[t, l, 0].to(torch.bfloat16).contiguous()
             cv = concept_vectors[t, l, 0].to(torch.bfloat16).contiguous()
             ops.heatmap_logits(iv, cv, logits)
-            ops.heatmap_softmax_accumulate(logits, acc, w)
+            ops.heatmap_softmax_accumulate(logits, acc, w, norm)
     side = int(round(math.sqrt(n_patches)))
     if side * side != n_patches:
         raise ValueError(f"{n_patches} patches do not form a square grid")

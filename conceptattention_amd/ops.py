@@ -265,13 +265,18 @@ def heatmap_logits(img_vec, con_vec, logits) -> None:
                                        _stream()), "ca_heatmap_logits_bf16")
 
 
-def heatmap_softmax_accumulate(logits, acc, weight: float) -> None:
+def heatmap_softmax_accumulate(logits, acc, weight: float, norm: int = L.NORM_SOFTMAX) -> None:
+    """acc += weight * norm_over_concepts(logits); norm: L.NORM_SOFTMAX | NORM_SPARSEMAX | NORM_ENTMAX15."""
     lib = L.load()
     _chk(logits, torch.float32, "logits"), _chk(acc, torch.float32, "acc")
     if logits.shape != acc.shape or not logits.is_contiguous() or not acc.is_contiguous():
         raise ValueError("heatmap_softmax_accumulate: logits/acc must be contiguous [C,L]")
-    L.check(lib.ca_heatmap_softmax_accumulate(logits.data_ptr(), logits.shape[0], logits.shape[1], weight,
-                                              acc.data_ptr(), _stream()), "ca_heatmap_softmax_accumulate")
+    if norm == L.NORM_SOFTMAX:
+        L.check(lib.ca_heatmap_softmax_accumulate(logits.data_ptr(), logits.shape[0], logits.shape[1], weight,
+                                                  acc.data_ptr(), _stream()), "ca_heatmap_softmax_accumulate")
+        return
+    L.check(lib.ca_heatmap_norm_accumulate(logits.data_ptr(), logits.shape[0], logits.shape[1], int(norm), weight,
+                                           acc.data_ptr(), _stream()), "ca_heatmap_norm_accumulate")
 
 
 def axpy(x, y, a: float) -> None:

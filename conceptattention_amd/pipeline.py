@@ -18,9 +18,9 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
-from . import sampling
+from . import _lib, sampling
 from .flux_dit import HeatmapRequest, HipFluxDiT, on_own_device
-from .heatmaps import compute_heatmaps_from_vectors
+from .heatmaps import compute_heatmaps_from_vectors, resolve_norm
 from .params import configs
 
 
@@ -124,15 +124,14 @@ class ConceptAttentionFluxPipeline:
         assert return_cross_attention is False, "Not supported yet"
         assert all([0 <= li < self.params.depth for li in layer_indices]), "Invalid layer index"
         assert height == width, "Height and width must be the same for now"
-        if not (softmax or attention_norm == "softmax"):
-            raise NotImplementedError("only the softmax branch is supported (entmax is unpinned)")
+        norm = resolve_norm(softmax, attention_norm)  # ValueError on an unknown name, as the reference (:70-71)
         if timesteps is None:
             timesteps = list(range(num_inference_steps))
         x = latent if latent is not None else sampling.get_noise(1, height, width, self.device, torch.bfloat16, seed)
         txt, vec, con, con_ids, con_vec = self._embed(prompt, concepts)
         img, concept_heatmaps, cross_attention_maps = self.generate_on_device(
             x, txt, vec, con, layer_indices=layer_indices, num_inference_steps=num_inference_steps,
-            guidance=guidance, timesteps=timesteps, fused=fused)
+            guidance=guidance, timesteps=timesteps, fused=fused, norm=norm)
         image = self._decode(img, height, width)
         return self._finish(image, concept_heatmaps, cross_attention_maps, return_pil_heatmaps, cmap)
 
@@ -153,6 +152,7 @@ class ConceptAttentionFluxPipeline:
         while len(self._streams) < n_streams:
             self._streams.append(torch.cuda.Stream(device=self.device))
         cur = torch.cuda.current_stream(self.device)
+        self.model.materialize()  # shared fp8 weight images: built on `cur`, which every side stream waits on
         results = [None] * len(items)
         for g0 in range(0, len(items), n_streams):
             group = list(range(g0, min(g0 + n_streams, len(items))))
@@ -184,9 +184,10 @@ class ConceptAttentionFluxPipeline:
     @torch.no_grad()
     @on_own_device
     def generate_on_device(self, latent, txt, vec, concept_embeddings, layer_indices=list(range(15, 19)),
-                           num_inference_steps: int = 4, guidance: float = 0.0, timesteps=None, fused: bool = True):
+                           num_inference_steps: int = 4, guidance: float = 0.0, timesteps=None, fused: bool = True,
+                           norm: int = 0):
         gen = self._generate_steps(self.model, latent, txt, vec, concept_embeddings, layer_indices,
-                                   num_inference_steps, guidance, timesteps, fused)
+                                   num_inference_steps, guidance, timesteps, fused, norm)
         while True:
             try:
                 next(gen)
@@ -194,7 +195,8 @@ class ConceptAttentionFluxPipeline:
                 return stop.value
 
     def _generate_steps(self, model, latent, txt, vec, concept_embeddings, layer_indices=list(range(15, 19)),
-                        num_inference_steps: int = 4, guidance: float = 0.0, timesteps=None, fused: bool = True):
+                        num_inference_steps: int = 4, guidance: float = 0.0, timesteps=None, fused: bool = True,
+                        norm: int = 0):
         """The device-resident core of generate_image: latent (1,16,h/8,w/8), txt (1,T,4096),
         vec (1,768), concept_embeddings (1,C,4096) already in HBM -> (final latent tokens,
         concept heat maps fp32 [1,C,side,side], cross-attention maps fp32 [1,C,side,side]) on the
@@ -207,12 +209,30 @@ class ConceptAttentionFluxPipeline:
         con, con_ids, con_vec = sampling.concept_inputs(concept_embeddings, vec)
         inp = sampling.prepare_from_embeddings(x, txt, vec)
         C, n_patches = con.shape[1], inp["img"].shape[1]
-        ts = [int(t) for t in timesteps]
+        # the reference indexes the stacked maps with `timesteps` (concept_attention_pipeline.py:76): an index
+        # outside [-steps, steps) is an IndexError there too; negative indices count from the end
+        ts = []
+        for t in timesteps:
+            t = int(t)
+            if not -num_inference_steps <= t < num_inference_steps:
+                raise IndexError(f"timestep index {t} is out of range for {num_inference_steps} inference steps")
+            ts.append(t % num_inference_steps)
         ls = [int(l) for l in layer_indices]
+        keep_before = model.keep_bf16_layers
         if model.precision == "fp8" and self.fp8_keep_heatmap_layers:
             # the double blocks whose attention outputs become heat maps stay in bf16: 4 of 57 blocks, no
             # measurable cost, and the maps move from 1.1e-2 to 1.8e-3 of the bf16 path
             model.set_precision("fp8", keep_bf16_layers=ls)
+        try:
+            return (yield from self._generate_steps_inner(model, x, inp, con, con_ids, con_vec, schedule, ts, ls,
+                                                          C, n_patches, guidance, layer_indices, timesteps, fused,
+                                                          norm))
+        finally:
+            model.keep_bf16_layers = keep_before  # this call's choice does not leak into later sweeps / encodes
+
+    def _generate_steps_inner(self, model, x, inp, con, con_ids, con_vec, schedule, ts, ls, C, n_patches, guidance,
+                              layer_indices, timesteps, fused, norm=0):
+        names = {v: k for k, v in _lib.NORMS.items()}
         # repeated indices weigh a (step, layer) pair repeatedly in the reference's fancy indexing
         # (concept_attention_pipeline.py:76-77); the fused accumulation covers distinct pairs only
         if fused and (len(set(ts)) != len(ts) or len(set(ls)) != len(ls)):
@@ -220,7 +240,7 @@ class ConceptAttentionFluxPipeline:
         if fused:
             req = HeatmapRequest(tuple(ls), 1.0 / (len(ts) * len(ls)),
                                  torch.zeros(C, n_patches, device=self.device),
-                                 torch.zeros(C, n_patches, device=self.device))
+                                 torch.zeros(C, n_patches, device=self.device), norm=norm)
             img, _, _ = yield from sampling.denoise_steps(
                 model, **inp, timesteps=schedule, guidance=guidance, concepts=con, concept_ids=con_ids,
                 concept_vec=con_vec, return_intermediate_images=False, return_vectors=False, heatmaps=req,
@@ -232,10 +252,10 @@ class ConceptAttentionFluxPipeline:
             concept_vec=con_vec, return_intermediate_images=False)
         cross_attention_maps = compute_heatmaps_from_vectors(
             d["cross_attention_image_vectors"], d["cross_attention_concept_vectors"],
-            layer_indices=layer_indices, timesteps=timesteps)
+            layer_indices=layer_indices, timesteps=timesteps, softmax=False, attention_norm=names[norm])
         concept_heatmaps = compute_heatmaps_from_vectors(
             d["output_space_image_vectors"], d["output_space_concept_vectors"],
-            layer_indices=layer_indices, timesteps=timesteps)
+            layer_indices=layer_indices, timesteps=timesteps, softmax=False, attention_norm=names[norm])
         return img, concept_heatmaps, cross_attention_maps
 
     # ------------------------------------------------------------------ per-layer x per-noise-level tables
@@ -295,8 +315,7 @@ class ConceptAttentionFluxPipeline:
         segmentation harness select the concept cross/self-attention ablations."""
         assert all([0 <= li < self.params.depth for li in layer_indices]), "Invalid layer index"
         assert height == width, "Height and width must be the same for now"
-        if not (softmax or attention_norm == "softmax"):
-            raise NotImplementedError("only the softmax branch is supported (entmax is unpinned)")
+        norm = resolve_norm(softmax, attention_norm)
         if isinstance(image, torch.Tensor):
             latent = image.to(self.device, torch.bfloat16)
         elif self.autoencoder is not None:
@@ -308,11 +327,12 @@ class ConceptAttentionFluxPipeline:
         txt, vec, con, con_ids, con_vec = self._embed(prompt, concepts)
         out_space, cross_space = self._encode_maps(self.model, latent, txt, vec, con, con_ids, con_vec, layer_indices,
                                                    num_samples, num_steps, noise_timestep, seed,
-                                                   stop_after_multi_modal_attentions, joint_attention_kwargs)
+                                                   stop_after_multi_modal_attentions, joint_attention_kwargs, norm)
         return self._finish(image, out_space, cross_space, return_pil_heatmaps, cmap)
 
     def _encode_maps(self, model, latent, txt, vec, con, con_ids, con_vec, layer_indices, num_samples, num_steps,
-                     noise_timestep, seed, stop_after_multi_modal_attentions=True, joint_attention_kwargs=None):
+                     noise_timestep, seed, stop_after_multi_modal_attentions=True, joint_attention_kwargs=None,
+                     norm: int = 0):
         """Device core of encode_image: one forward per noise sample on ``model``; returns the two fp32 maps
         [1, C, side, side]."""
         C = con.shape[1]
@@ -323,7 +343,7 @@ class ConceptAttentionFluxPipeline:
         # a value >= 1; here every sample contributes equally (identical at num_samples=1).
         req = HeatmapRequest(tuple(int(l) for l in layer_indices), 1.0 / (num_samples * len(layer_indices)),
                              torch.zeros(C, n_patches, device=self.device),
-                             torch.zeros(C, n_patches, device=self.device))
+                             torch.zeros(C, n_patches, device=self.device), norm=norm)
         schedule = sampling.get_schedule(num_steps, n_patches, shift=(not self.is_schnell))
         for i in range(num_samples):
             # add_noise_to_image (concept_attention/segmentation.py:85-113)
@@ -358,6 +378,7 @@ class ConceptAttentionFluxPipeline:
         while len(self._streams) < n_streams:
             self._streams.append(torch.cuda.Stream(device=self.device))
         cur = torch.cuda.current_stream(self.device)
+        self.model.materialize()  # shared fp8 weight images: built on `cur`, which every side stream waits on
         for st in self._streams[:n_streams]:
             st.wait_stream(cur)
         results = []

@@ -57,12 +57,27 @@ def unpack(x: torch.Tensor, height: int, width: int) -> torch.Tensor:
     return x.view(b, h, w, c, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(b, c, h * 2, w * 2)
 
 
+def _tag_ids(t: torch.Tensor, what: tuple) -> torch.Tensor:
+    """Mark an id tensor with what it holds, so HipFluxDiT may cache the RoPE table by content (the tag is void
+    once the tensor's version counter moves)."""
+    try:
+        t._ca_ids_tag = (what, t._version)
+    except RuntimeError:  # inference mode: no version counter -> no tag -> table rebuilt per forward
+        pass
+    return t
+
+
 def make_img_ids(h2: int, w2: int, device=None) -> torch.Tensor:
     """img_ids of prepare() (flux/sampling.py:40-43): [0, row, col] per token."""
     ids = torch.zeros(h2, w2, 3, device=device)
     ids[..., 1] = torch.arange(h2, device=device)[:, None]
     ids[..., 2] = torch.arange(w2, device=device)[None, :]
-    return ids.reshape(1, h2 * w2, 3)
+    return _tag_ids(ids.reshape(1, h2 * w2, 3), ("img", h2, w2))
+
+
+def zero_ids(n: int, device=None) -> torch.Tensor:
+    """txt_ids of prepare() (flux/sampling.py:50) and concept_ids of embed_concepts (utils.py:26): all zero."""
+    return _tag_ids(torch.zeros(1, n, 3, device=device), ("zero", n))
 
 
 def prepare_from_embeddings(img: torch.Tensor, txt: torch.Tensor, vec: torch.Tensor) -> dict:
@@ -75,7 +90,7 @@ def prepare_from_embeddings(img: torch.Tensor, txt: torch.Tensor, vec: torch.Ten
         "img": patchify(img),
         "img_ids": make_img_ids(h // 2, w // 2, img.device),
         "txt": txt.to(img.device),
-        "txt_ids": torch.zeros(bs, txt.shape[1], 3, device=img.device),
+        "txt_ids": zero_ids(txt.shape[1], img.device),
         "vec": vec.to(img.device),
     }
 
@@ -84,8 +99,7 @@ def concept_inputs(concept_embeddings: torch.Tensor, vec_like: torch.Tensor):
     """embed_concepts' output contract (concept_attention/utils.py:6-33): first-token embeddings
     (1,C,4096), all-zero ids (1,C,3) and an all-ZERO pooled vector."""
     c = concept_embeddings.shape[1]
-    return (concept_embeddings, torch.zeros(1, c, 3, device=concept_embeddings.device),
-            torch.zeros_like(vec_like))
+    return (concept_embeddings, zero_ids(c, concept_embeddings.device), torch.zeros_like(vec_like))
 
 
 @torch.no_grad()

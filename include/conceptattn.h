@@ -200,6 +200,17 @@ int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const void *con_vec
                            ca_stream_t stream);
 int ca_heatmap_softmax_accumulate(const float *logits, int32_t C, int32_t L, float weight, float *acc,
                                   ca_stream_t stream);
+/* The same accumulation with the other two weightings across concepts the reference offers
+ * (`attention_norm`, concept_attention_pipeline.py:33,64-71): norm = CA_NORM_SOFTMAX (as above),
+ * CA_NORM_SPARSEMAX or CA_NORM_ENTMAX15.  The reference takes the latter two from the third-party `entmax`
+ * package, which it neither pins nor vendors: they are implemented here from the published algorithms
+ * (Martins & Astudillo 2016; Peters, Niculae & Martins 2019) and their parity with that package is UNPINNED.
+ * The sparse norms need C <= 16. */
+#define CA_NORM_SOFTMAX 0
+#define CA_NORM_SPARSEMAX 1
+#define CA_NORM_ENTMAX15 2
+int ca_heatmap_norm_accumulate(const float *logits, int32_t C, int32_t L, int32_t norm, float weight, float *acc,
+                               ca_stream_t stream);
 
 /* Sinusoidal timestep embedding (timestep_embedding, flux/modules/layers.py:28-49):
  * out[v, 0:dim/2] = cos(time_factor*t[v]*f_i), out[v, dim/2:] = sin(...), f_i = max_period^(-i/(dim/2)). */

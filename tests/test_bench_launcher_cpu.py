@@ -1,0 +1,42 @@
+"""`python bench.py --gpus N` must start its own ranks (the driver's SCALE command has no outer launcher).
+
+Runs the real self-launch path of bench.py -- parent spawns N children through torch.distributed.run, ranks
+rendezvous on 127.0.0.1, shard the items, gather, rank 0 prints ONE JSON line, the parent relays it and exits
+with the children's code -- on the CPU with gloo and --stub-workload (constant tensors instead of GPU work)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None, timeout=300):
+    env = dict(os.environ, CA_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_self_launch_two_ranks_prints_one_json_line():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--stub-workload"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["gathered_in_item_order"] is True
+    assert out["data"] == "stub" and out["metric"].startswith("STUB")
+
+
+def test_self_launch_propagates_child_failure():
+    # a rank that dies (unknown flag -> argparse exit 2 in every child) must make the parent exit non-zero
+    r = _run(["--gpus", "2", "--stub-workload", "--no-such-flag"])
+    assert r.returncode != 0
+
+
+def test_world_size_mismatch_is_rejected():
+    r = _run(["--gpus", "1", "--stub-workload"], {"WORLD_SIZE": "2", "RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                                  "MASTER_PORT": "1"}, timeout=120)
+    assert r.returncode != 0

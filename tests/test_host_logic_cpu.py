@@ -61,11 +61,18 @@ def test_params_validation_matches_reference_errors():
     assert configs["flux-dev"].guidance_embed and not configs["flux-schnell"].guidance_embed
 
 
-def test_heatmap_api_rejects_unpinned_norms_without_gpu():
-    from conceptattention_amd.heatmaps import compute_heatmaps_from_vectors, linear_normalization
+def test_heatmap_norm_selection_follows_the_reference_branch_order():
+    """concept_attention_pipeline.py:64-71: softmax if `softmax` or attention_norm == "softmax", else entmax15 /
+    sparsemax, else ValueError (raised before anything touches the GPU)."""
+    from conceptattention_amd import _lib
+    from conceptattention_amd.heatmaps import compute_heatmaps_from_vectors, linear_normalization, resolve_norm
+    assert resolve_norm(True, "sparsemax") == _lib.NORM_SOFTMAX      # the reference's defaults
+    assert resolve_norm(False, "softmax") == _lib.NORM_SOFTMAX
+    assert resolve_norm(False, "sparsemax") == _lib.NORM_SPARSEMAX
+    assert resolve_norm(False, "entmax15") == _lib.NORM_ENTMAX15
     iv, cv = torch.zeros(1, 1, 1, 4, 8), torch.zeros(1, 1, 1, 2, 8)
-    with pytest.raises(NotImplementedError):
-        compute_heatmaps_from_vectors(iv, cv, [0], [0], softmax=False, attention_norm="sparsemax")
+    with pytest.raises(ValueError):
+        compute_heatmaps_from_vectors(iv, cv, [0], [0], softmax=False, attention_norm="nope")
     x = torch.tensor([[1.0, 3.0], [2.0, 2.0]])
     n = linear_normalization(x, dim=0)
     assert torch.allclose(n.sum(0), torch.tensor([1.0, 1.0]))
