@@ -217,6 +217,17 @@ def main():
         e.record()
         records.append((tile, fl, s, e))
 
+    attn_records = []
+
+    def attn_hook(arr, num_heads, launch):
+        # algorithmic FLOPs of the launch: 4 * Nq * Nk * 128 * heads per problem
+        fl = sum(4.0 * arr[i].nq * (arr[i].n0 + arr[i].n1) * 128 * num_heads for i in range(len(arr)))
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        attn_records.append((fl, s, e))
+
     torch.cuda.synchronize()
     D.barrier()
     t0 = time.perf_counter()
@@ -231,8 +242,10 @@ def main():
         local_maps += [run_item(j) for j in head]
     if not args.no_kernel_timing:
         ops.set_gemm_hook(hook)
+        ops.set_attn_hook(attn_hook)
     local_maps.append(run_item(last))
     ops.set_gemm_hook(None)
+    ops.set_attn_hook(None)
     local_maps = torch.stack(local_maps)
     # the one collective of the job: gather the small fp32 maps of all ranks in item order (RCCL over xGMI)
     all_maps = D.gather_heatmaps(local_maps, n_timed, rank, world)
@@ -311,13 +324,30 @@ def main():
         # so this is the rocprofv3 FETCH_SIZE/WRITE_SIZE measurement of this same command, committed
         # under profiles/ (method and the gfx950 x2 FETCH_SIZE correction are recorded in the file)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
+            import glob
+            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]
+            pmc_doc = json.load(open(pmc_file))
+            pmc = pmc_doc["kernels"]
             key = roof.get("kernel", "").split(" ")[0]
             if key in pmc and not fp8:
                 roof["traffic"] = pmc[key]["bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)"
+                roof["traffic_source"] = (f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                          f"passes of this command at {pmc_doc.get('git_head', 'an earlier commit')}; "
+                                          "counters cannot be read from inside the process)")
+            if roof_attn is not None and "ca_attn_kernel<8>" in pmc and not fp8:
+                roof_attn["traffic"] = pmc["ca_attn_kernel<8>"]["bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        roof_attn = None
+        if attn_records:   # second MFMA kernel of the path, timed the same way on the same solo step
+            fl = sum(r[0] for r in attn_records)
+            sec = sum(r[1].elapsed_time(r[2]) for r in attn_records) * 1e-3
+            roof_attn = {"bound": "mfma", "kernel": "ca_attn_kernel<8> (256 query rows x 64-key tiles)",
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": len(attn_records),
+                         "avg_launch_us": sec / len(attn_records) * 1e6, "flops_per_launch": fl / len(attn_records),
+                         "achieved": fl / sec / 1e12, "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                         "share_of_that_step": sec / (elapsed / max(len(timed_items), 1)),
+                         "timed_on": "last timed step of rank 0", "traffic": None}
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["path_achieved"] = path_tflops
         roof["path_frac"] = path_tflops / MFMA_BF16_PEAK_TFLOPS
@@ -344,6 +374,7 @@ def main():
             "calls_per_s": calls / elapsed,
             "outputs_finite_and_normalised": maps_ok,
             "roofline": roof,
+            "roofline_attention": roof_attn,
             "concept_attention_block": block,
         }
         if world == 1 and not args.no_cpu_baseline:

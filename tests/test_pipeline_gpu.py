@@ -89,8 +89,9 @@ def test_generate_image_argument_checks(pipe):
         pipe.generate_image("p", ["a"], width=256, height=256, layer_indices=[7])
     with pytest.raises(AssertionError):
         pipe.generate_image("p", ["a"], width=256, height=256, return_cross_attention=True)
-    with pytest.raises(NotImplementedError):
-        pipe.generate_image("p", ["a"], width=256, height=256, layer_indices=[0], softmax=False)
+    with pytest.raises(ValueError):  # concept_attention_pipeline.py:70-71
+        pipe.generate_image("p", ["a"], width=256, height=256, layer_indices=[0], softmax=False,
+                            attention_norm="unknown")
 
 
 def test_encode_image_runs_double_blocks_only(pipe):

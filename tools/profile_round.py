@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""One command that produces every profile the bench line's roofline numbers rest on, stamped with the git HEAD.
+
+    python tools/profile_round.py --round 2            # in the build container: drives ONE gpurun call
+    python tools/profile_round.py --on-box --round 2   # what that call executes on the GPU box
+
+On the box, for the exact bench command (`python3 bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline
+--no-kernel-timing`; one stream so that per-kernel durations are exclusive):
+  1. rocprofv3 --kernel-trace --stats                       -> profiles/rNN_rocprofv3_kernel_stats.csv
+  2. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace
+                                                            -> profiles/rNN_pmc_mfma_busy.json
+  3. rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes: the TCC block holds one of them at a
+     time, MI355X_MICROARCH.md)                             -> profiles/rNN_pmc_hbm_traffic.json
+  4. the un-profiled default bench line                     -> profiles/rNN_bench_default.json
+Counter passes never combine --pmc with sys/hip/hsa tracing.  The summaries carry {"git_head": ...}; bench.py reads
+`roofline.traffic` from the newest rNN_pmc_hbm_traffic.json.
+"""
+import argparse
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = ["python3", "bench.py", "--steps", "2", "--warmup", "1", "--streams", "1", "--no-cpu-baseline",
+         "--no-kernel-timing"]
+
+
+def sh(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    return subprocess.run(cmd, **kw)
+
+
+def on_box(rnd: int, head: str):
+    tag = f"r{rnd:02d}"
+    out = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    env = dict(os.environ, TMPDIR="/tmp")
+    os.chdir(ROOT)
+    # 1. kernel trace + stats
+    d = os.path.join(out, "trace")
+    sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + BENCH, env=env,
+       stdout=open(os.path.join(out, "trace.log"), "w"), stderr=subprocess.STDOUT, check=True)
+    stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    lines = open(stats[0]).read().splitlines()
+    with open(os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"), "w") as f:
+        f.write(f"# git_head {head}; command: rocprofv3 --kernel-trace --stats -- {' '.join(BENCH)}\n")
+        f.write("\n".join(lines[:40]) + "\n")
+    # 2. MFMA busy
+    d = os.path.join(out, "pmc_mfma")
+    sh(["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace",
+        "--output-format", "csv", "-d", d, "--"] + BENCH, env=env,
+       stdout=open(os.path.join(out, "pmc_mfma.log"), "w"), stderr=subprocess.STDOUT, check=True)
+    j = os.path.join(out, f"{tag}_pmc_mfma_busy.json")
+    sh([sys.executable, "tools/pmc_summary.py", d, j], check=True)
+    doc = {"git_head": head, "command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE "
+           "--kernel-trace -- " + " ".join(BENCH), "kernels": json.load(open(j))}
+    json.dump(doc, open(j, "w"), indent=1, sort_keys=True)
+    # 3. HBM-side traffic, one counter per pass
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        sh(["rocprofv3", "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, "pmc_" + c),
+            "--"] + BENCH, env=env, stdout=open(os.path.join(out, f"pmc_{c}.log"), "w"), stderr=subprocess.STDOUT,
+           check=True)
+    j = os.path.join(out, f"{tag}_pmc_hbm_traffic.json")
+    sh([sys.executable, "tools/pmc_hbm_traffic.py", os.path.join(out, "pmc_FETCH_SIZE"),
+        os.path.join(out, "pmc_WRITE_SIZE"), j], check=True)
+    doc = json.load(open(j))
+    doc["git_head"] = head
+    json.dump(doc, open(j, "w"), indent=1)
+    # 4. the default, un-profiled bench line (two streams, per-launch HIP-event timing on the last step)
+    r = sh(["python3", "bench.py", "--steps", "8", "--warmup", "1"], env=env, capture_output=True, text=True, check=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    doc = json.loads(line)
+    doc["git_head"] = head
+    json.dump(doc, open(os.path.join(out, f"{tag}_bench_default.json"), "w"), indent=1)
+    for big in ("trace", "pmc_mfma", "pmc_FETCH_SIZE", "pmc_WRITE_SIZE"):  # raw traces stay on the box
+        shutil.rmtree(os.path.join(out, big), ignore_errors=True)
+    print("profiles written to", out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", type=int, required=True)
+    ap.add_argument("--on-box", action="store_true")
+    ap.add_argument("--head", default="")
+    a = ap.parse_args()
+    if a.on_box:
+        return on_box(a.round, a.head)
+    head = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, text=True).strip()
+    if subprocess.check_output(["git", "status", "--porcelain"], cwd=ROOT, text=True).strip():
+        head += "+dirty"
+    cmd = f"python3 tools/profile_round.py --on-box --round {a.round} --head {head} > gpurun_out/profile_round.log 2>&1"
+    rc = sh(["/usr/local/graft/bin/gpurun", "--timeout", "900", "--", cmd]).returncode
+    tag = f"r{a.round:02d}"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    for f in glob.glob(os.path.join(src, f"{tag}_*")):
+        shutil.copy(f, os.path.join(ROOT, "profiles", os.path.basename(f)))
+        print("copied", os.path.basename(f))
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    main()
