@@ -320,6 +320,16 @@ def main():
                         share_of_that_step=sec / (elapsed / max(len(timed_items), 1)))
         else:
             roof.update(kernel="whole path", achieved=path_tflops)
+        roof_attn = None
+        if attn_records:   # second MFMA kernel of the path, timed the same way on the same solo step
+            fl = sum(r[0] for r in attn_records)
+            sec = sum(r[1].elapsed_time(r[2]) for r in attn_records) * 1e-3
+            roof_attn = {"bound": "mfma", "kernel": "ca_attn_kernel<8> (256 query rows x 64-key tiles)",
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": len(attn_records),
+                         "avg_launch_us": sec / len(attn_records) * 1e6, "flops_per_launch": fl / len(attn_records),
+                         "achieved": fl / sec / 1e12, "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                         "share_of_that_step": sec / (elapsed / max(len(timed_items), 1)),
+                         "timed_on": "last timed step of rank 0", "traffic": None}
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside the process,
         # so this is the rocprofv3 FETCH_SIZE/WRITE_SIZE measurement of this same command, committed
         # under profiles/ (method and the gfx950 x2 FETCH_SIZE correction are recorded in the file)
@@ -338,16 +348,6 @@ def main():
                 roof_attn["traffic"] = pmc["ca_attn_kernel<8>"]["bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        roof_attn = None
-        if attn_records:   # second MFMA kernel of the path, timed the same way on the same solo step
-            fl = sum(r[0] for r in attn_records)
-            sec = sum(r[1].elapsed_time(r[2]) for r in attn_records) * 1e-3
-            roof_attn = {"bound": "mfma", "kernel": "ca_attn_kernel<8> (256 query rows x 64-key tiles)",
-                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": len(attn_records),
-                         "avg_launch_us": sec / len(attn_records) * 1e6, "flops_per_launch": fl / len(attn_records),
-                         "achieved": fl / sec / 1e12, "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                         "share_of_that_step": sec / (elapsed / max(len(timed_items), 1)),
-                         "timed_on": "last timed step of rank 0", "traffic": None}
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["path_achieved"] = path_tflops
         roof["path_frac"] = path_tflops / MFMA_BF16_PEAK_TFLOPS
