@@ -558,7 +558,9 @@ class HipFluxDiT:
             # the reference stores post-QKNorm, pre-RoPE q per head: [B, heads, tokens, 128]; in the
             # self-attention-only ablation it rebinds concept_q to the post-RoPE tensor (:140), which
             # for the all-zero concept ids is the same values
-            cq = QPRE[:C].view(C, NH, 128).permute(1, 0, 2).contiguous()[None]
-            iq = QPRE[CT:].view(n - CT, NH, 128).permute(1, 0, 2).contiguous()[None]
+            # (clone, not .contiguous(): for C = 1 the permuted view already counts as contiguous and would keep
+            # aliasing QPRE, which the next block overwrites)
+            cq = QPRE[:C].view(C, NH, 128).permute(1, 0, 2).clone(memory_format=torch.contiguous_format)[None]
+            iq = QPRE[CT:].view(n - CT, NH, 128).permute(1, 0, 2).clone(memory_format=torch.contiguous_format)[None]
             out["cross_attention_concept_vectors"].append(cq)
             out["cross_attention_image_vectors"].append(iq)
