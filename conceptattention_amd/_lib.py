@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconceptattn.so")
 
-CA_VERSION = 100
+CA_VERSION = 110
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU, EPI_QKV_NORM_ROPE = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_256x256, TILE_256x192, TILE_256x128, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_PP_256x256, TILE_PP_256x128, TILE_PP_256x192 = 5, 6, 7
@@ -29,7 +29,7 @@ class GemmProblem(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("ld2", C.c_int32), ("n_split", C.c_int32), ("gate_rows", C.c_int32),
-                ("epilogue", C.c_int32), ("ldp", C.c_int32)]
+                ("epilogue", C.c_int32), ("ldp", C.c_int32), ("out_f32", C.c_int32), ("_pad", C.c_int32)]
 
 
 class AttnProblem(C.Structure):
@@ -60,6 +60,10 @@ SIGNATURES = {
                                       C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),
     "ca_ln_modulate_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                      C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),
+    "ca_ln_modulate_f32in": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),
+    "ca_ln_modulate_f32in_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),
     "ca_quantize_rows_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p]),
     "ca_qknorm_rope_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(NormSegment),

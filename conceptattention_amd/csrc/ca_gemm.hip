@@ -208,6 +208,24 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_kernel(const GemmLaunch L) {
       const int m = mrow0 + 16 * i;
       if (m < M) {
         const bool first = m < P.gate_rows;
+        if (P.out_f32) {  // fp32 residual stream: 16 bytes per 4 columns, read and written in place
+          const f32x4 *rp = (const f32x4 *)(resb + ((size_t)m * P.ldr + nb) * 4);
+          f32x4 *op = (f32x4 *)(outb + ((size_t)m * ldo + ncol) * 4);
+          f32x4 res[N_REP];
+#pragma unroll
+          for (int j = 0; j < N_REP; ++j) res[j] = rp[j];
+#pragma unroll
+          for (int j = 0; j < N_REP; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float gt = first ? gate_a[4 * j + r] : gate_b[4 * j + r];
+              v[r] = res[j][r] + gt * (acc[i][j][r] + bias[4 * j + r]);
+            }
+            op[j] = v;
+          }
+          continue;
+        }
         const uint2 *rp = (const uint2 *)(resb + ((size_t)m * P.ldr + nb) * 2);
         uint2 *op = (uint2 *)(outb + ((size_t)m * ldo + ncol) * 2);
         uint2 res[N_REP];
@@ -227,11 +245,13 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_kernel(const GemmLaunch L) {
       }
     }
   } else {
+    const bool f32o = P.out_f32 && epi == CA_EPI_BIAS;
 #pragma unroll
     for (int i = 0; i < M_REP; ++i) {
       const int m = mrow0 + 16 * i;
       if (m < M) {
         uint2 *op = (uint2 *)(outb + ((size_t)m * ldo + ncol) * 2);
+        f32x4 *op32 = (f32x4 *)(outb + ((size_t)m * ldo + ncol) * 4);
 #pragma unroll
         for (int j = 0; j < N_REP; ++j) {
           float v[4];
@@ -240,7 +260,8 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_kernel(const GemmLaunch L) {
             v[r] = acc[i][j][r] + bias[4 * j + r];
             if (epi == CA_EPI_GELU_TANH) v[r] = ca_gelu_tanh(v[r]);
           }
-          op[j] = make_uint2(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]));
+          if (f32o) op32[j] = f32x4{v[0], v[1], v[2], v[3]};
+          else op[j] = make_uint2(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]));
         }
       }
     }
@@ -642,6 +663,43 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     }
     // the residual rows are fetched up front for all 8 row fragments (rows clamped, only the store is
     // predicated): one round trip to memory instead of eight dependent ones
+    if (P.out_f32 && (epi == CA_EPI_GATE_RESIDUAL || epi == CA_EPI_BIAS)) {
+      // fp32 output (the residual stream): a lane's 4*NF columns are 16*NF bytes; GATE_RESIDUAL reads the old
+      // value of the same element first.  Four row fragments are fetched up front (32*NF bytes per lane each).
+      const bool gated = epi == CA_EPI_GATE_RESIDUAL;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        f32x4 r32[4][NF];
+        if (gated) {
+#pragma unroll
+          for (int mq = 0; mq < 4; ++mq) {
+            const int mi = mh * 4 + mq;
+            const int m = min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1);
+            const f32x4 *rp = (const f32x4 *)((const char *)P.resid + ((size_t)m * P.ldr + nb) * 4);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) r32[mq][j] = rp[j];
+          }
+        }
+#pragma unroll
+        for (int mq = 0; mq < 4; ++mq) {
+          const int mi = mh * 4 + mq;
+          const int m = m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
+          const bool first = m < P.gate_rows;
+          f32x4 *op = (f32x4 *)(outb + ((size_t)m * ldo + nb + col_shift) * 4);
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[mi][nj0 + j][r] + bias[4 * j + r];
+              if (gated) v[r] = r32[mq][j][r] + (first ? gate_a[4 * j + r] : gate_b[4 * j + r]) * v[r];
+            }
+            if (m < M) op[j] = v;
+          }
+        }
+      }
+      return;
+    }
     uint2 res[8][NF];
     if (epi == CA_EPI_GATE_RESIDUAL) {
 #pragma unroll
@@ -849,7 +907,7 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
       ca_set_error("%s[%d]: null pointer or empty shape (M=%d N=%d K=%d)", FN, i, p.M, p.N, p.K);
       return CA_ERR_ARG;
     }
-    if (p.K % kq || p.N % bn || p.lda % ldq || p.ldw % ldq || p.ldc % 8) {
+    if (p.K % kq || p.N % bn || p.lda % ldq || p.ldw % ldq || (p.ldc % 8 && !p.out_f32)) {
       ca_set_error("%s[%d]: need K%%%d==0, N%%%d==0, lda/ldw%%%d==0, ldc%%8==0 (M=%d N=%d K=%d lda=%d ldw=%d ldc=%d)",
                    FN, i, kq, bn, ldq, p.M, p.N, p.K, p.lda, p.ldw, p.ldc);
       return CA_ERR_ARG;
@@ -870,13 +928,18 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
       ca_set_error("%s[%d]: operand larger than 4 GiB", FN, i);
       return CA_ERR_ARG;
     }
+    if (p.out_f32 && ((p.epilogue != CA_EPI_BIAS && p.epilogue != CA_EPI_GATE_RESIDUAL) || p.ldc % 4 ||
+                      (p.epilogue == CA_EPI_GATE_RESIDUAL && p.ldr % 4))) {
+      ca_set_error("%s[%d]: out_f32 needs the BIAS or GATE_RESIDUAL epilogue and ldc/ldr %% 4 == 0", FN, i);
+      return CA_ERR_ARG;
+    }
     switch (p.epilogue) {
       case CA_EPI_BIAS:
       case CA_EPI_GELU_TANH:
         if (p.ldc < p.N) { ca_set_error("%s[%d]: ldc < N", FN, i); return CA_ERR_ARG; }
         break;
       case CA_EPI_GATE_RESIDUAL:
-        if (!p.resid || !p.gate || p.ldr % 8 || p.ldc < p.N || ((uintptr_t)p.resid & 15) ||
+        if (!p.resid || !p.gate || (p.ldr % 8 && !p.out_f32) || p.ldc < p.N || ((uintptr_t)p.resid & 15) ||
             ((uintptr_t)p.gate & 15) || ((uintptr_t)p.gate2 & 15) || (p.gate_rows < p.M && !p.gate2)) {
           ca_set_error("%s[%d]: GATE_RESIDUAL needs resid, gate (and gate2 when gate_rows < M), 16-byte aligned", FN, i);
           return CA_ERR_ARG;

@@ -3,6 +3,7 @@
 // All use 16-byte-per-lane coalesced accesses and fp32 arithmetic; none of them is shaped into
 // an MFMA product (they are bandwidth-bound: see DESIGN.md for bytes per unit).
 #include <atomic>
+#include <type_traits>
 
 #include "ca_common.h"
 
@@ -45,8 +46,8 @@ __device__ __forceinline__ uint2 ca_pack_fp8x8(const float *y) {
 
 // FP8: the modulated row is quantised to e4m3 with one absmax scale per row (out8 row stride ldo BYTES,
 // out_scale[row] = absmax / 448): the A operand of ca_gemm_fp8.
-template <bool FP8>
-__global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const bf16 *__restrict__ x, int ldx,
+template <bool FP8, typename XT = bf16>
+__global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const XT *__restrict__ x, int ldx,
                                                              void *__restrict__ out_, int ldo, int M, int H,
                                                              float eps, float *__restrict__ out_scale,
                                                              const LnArgs A) {
@@ -60,19 +61,27 @@ __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const bf16 *__restr
   const float *shift = A.seg[si].shift;
   const float *scale = A.seg[si].scale;
 
-  const bf16 *xr = x + (size_t)row * ldx;
+  const XT *xr = x + (size_t)row * ldx;
   float v[LN_MAXCH][8];
   float sum = 0.f;
 #pragma unroll
   for (int c = 0; c < LN_MAXCH; ++c) {
     const int k = c * 512 + lane * 8;
     if (k < H) {
-      const bf16x8 t = *(const bf16x8 *)(xr + k);
+      if constexpr (std::is_same<XT, float>::value) {
+        const f32x4 t0 = *(const f32x4 *)(xr + k), t1 = *(const f32x4 *)(xr + k + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[c][j] = (float)t[j];
-        sum += v[c][j];
+        for (int j = 0; j < 4; ++j) {
+          v[c][j] = t0[j];
+          v[c][4 + j] = t1[j];
+        }
+      } else {
+        const bf16x8 t = *(const bf16x8 *)(xr + k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[c][j] = (float)t[j];
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[c][j];
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
@@ -459,10 +468,11 @@ int check_launch(const char *what) {
 
 namespace {
 int ln_modulate_impl(const char *FN, const void *x, int32_t ldx, void *out, int32_t ldo, float *out_scale, int32_t M,
-                     int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream) {
+                     int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream,
+                     bool x_f32 = false) {
   const bool fp8 = out_scale != nullptr;
   if (!x || !out || !segs || M < 1 || H < 8 || H % 8 || H > LN_MAXCH * 512 || n_segs < 1 ||
-      n_segs > CA_MAX_SEGMENTS || ldx % 8 || ldo % (fp8 ? 16 : 8) || ldx < H || ldo < H ||
+      n_segs > CA_MAX_SEGMENTS || ldx % (x_f32 ? 4 : 8) || ldo % (fp8 ? 16 : 8) || ldx < H || ldo < H ||
       (((uintptr_t)x | (uintptr_t)out) & 15) || ((uintptr_t)out_scale & 3)) {
     ca_set_error("%s: bad arguments (M=%d H=%d n_segs=%d ldx=%d ldo=%d; need H%%8==0, H<=%d)", FN, M, H, n_segs, ldx,
                  ldo, LN_MAXCH * 512);
@@ -484,12 +494,20 @@ int ln_modulate_impl(const char *FN, const void *x, int32_t ldx, void *out, int3
     ca_set_error("%s: segments cover %d rows, M=%d", FN, prev, M);
     return CA_ERR_ARG;
   }
-  if (fp8)
-    hipLaunchKernelGGL(ca_ln_modulate_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16 *)x, ldx, out, ldo, M, H, eps, out_scale, A);
+  const dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (x_f32 && fp8)
+    hipLaunchKernelGGL((ca_ln_modulate_kernel<true, float>), grid, block, 0, st, (const float *)x, ldx, out, ldo, M, H,
+                       eps, out_scale, A);
+  else if (x_f32)
+    hipLaunchKernelGGL((ca_ln_modulate_kernel<false, float>), grid, block, 0, st, (const float *)x, ldx, out, ldo, M,
+                       H, eps, (float *)nullptr, A);
+  else if (fp8)
+    hipLaunchKernelGGL((ca_ln_modulate_kernel<true, bf16>), grid, block, 0, st, (const bf16 *)x, ldx, out, ldo, M, H,
+                       eps, out_scale, A);
   else
-    hipLaunchKernelGGL(ca_ln_modulate_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16 *)x, ldx, out, ldo, M, H, eps, (float *)nullptr, A);
+    hipLaunchKernelGGL((ca_ln_modulate_kernel<false, bf16>), grid, block, 0, st, (const bf16 *)x, ldx, out, ldo, M, H,
+                       eps, (float *)nullptr, A);
   return check_launch(FN);
 }
 }  // namespace
@@ -507,6 +525,22 @@ extern "C" int ca_ln_modulate_fp8(const void *x, int32_t ldx, void *out8, int32_
     return CA_ERR_ARG;
   }
   return ln_modulate_impl("ca_ln_modulate_fp8", x, ldx, out8, ldo, out_scale, M, H, segs, n_segs, eps, stream);
+}
+
+extern "C" int ca_ln_modulate_f32in(const float *x, int32_t ldx, void *out, int32_t ldo, int32_t M, int32_t H,
+                                    const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream) {
+  return ln_modulate_impl("ca_ln_modulate_f32in", x, ldx, out, ldo, nullptr, M, H, segs, n_segs, eps, stream, true);
+}
+
+extern "C" int ca_ln_modulate_f32in_fp8(const float *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale,
+                                        int32_t M, int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps,
+                                        ca_stream_t stream) {
+  if (!out_scale) {
+    ca_set_error("ca_ln_modulate_f32in_fp8: out_scale is NULL");
+    return CA_ERR_ARG;
+  }
+  return ln_modulate_impl("ca_ln_modulate_f32in_fp8", x, ldx, out8, ldo, out_scale, M, H, segs, n_segs, eps, stream,
+                          true);
 }
 
 extern "C" int ca_quantize_rows_fp8(const void *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale, int32_t M,

@@ -61,7 +61,8 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
     fp8 = problems[0].a.dtype == torch.uint8
     op_dtype = torch.uint8 if fp8 else torch.bfloat16
     for i, g in enumerate(problems):
-        a, w, out = _chk(g.a, op_dtype, "a"), _chk(g.w, op_dtype, "w"), _chk(g.out, torch.bfloat16, "out")
+        f32o = g.out.dtype == torch.float32  # the fp32 residual stream (BIAS / GATE_RESIDUAL epilogues)
+        a, w, out = _chk(g.a, op_dtype, "a"), _chk(g.w, op_dtype, "w"), _chk(g.out, g.out.dtype if f32o else torch.bfloat16, "out")
         if fp8:
             if g.a_scale is None or g.w_scale is None:
                 raise ValueError(f"gemm[{i}]: fp8 operands need a_scale and w_scale")
@@ -77,11 +78,12 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
         p.M, p.N, p.K = a.shape[0], w.shape[0], a.shape[1]
         p.lda, p.ldw, p.ldc = a.stride(0), w.stride(0), out.stride(0)
         p.epilogue = g.epilogue
+        p.out_f32 = int(f32o)
         p.gate_rows = p.M if g.gate_rows is None else g.gate_rows
         if g.epilogue == L.EPI_GATE_RESIDUAL:
             if g.resid is None or g.gate is None:
                 raise ValueError(f"gemm[{i}]: GATE_RESIDUAL needs resid and gate")
-            p.resid, p.ldr = _chk(g.resid, torch.bfloat16, "resid").data_ptr(), g.resid.stride(0)
+            p.resid, p.ldr = _chk(g.resid, out.dtype, "resid").data_ptr(), g.resid.stride(0)
             p.gate = _chk(g.gate, torch.float32, "gate").data_ptr()
             p.gate2 = _ptr(None if g.gate2 is None else _chk(g.gate2, torch.float32, "gate2"))
         elif g.epilogue == L.EPI_QKV_NORM_ROPE:
@@ -194,7 +196,8 @@ def ln_modulate(x, out, segments, eps: float = 1e-6, out_scale=None) -> None:
     With ``out`` uint8 and ``out_scale`` fp32 [M] the result is quantised to e4m3 per row (ca_ln_modulate_fp8)."""
     lib = L.load()
     fp8 = out.dtype == torch.uint8
-    _chk(x, torch.bfloat16, "x"), _chk(out, torch.uint8 if fp8 else torch.bfloat16, "out")
+    x32 = x.dtype == torch.float32   # fp32 residual stream
+    _chk(x, torch.float32 if x32 else torch.bfloat16, "x"), _chk(out, torch.uint8 if fp8 else torch.bfloat16, "out")
     if fp8 and (out_scale is None or out_scale.dtype != torch.float32 or out_scale.numel() != x.shape[0]
                 or not out_scale.is_contiguous()):
         raise ValueError("ln_modulate: fp8 output needs a contiguous fp32 out_scale [M]")
@@ -206,12 +209,13 @@ def ln_modulate(x, out, segments, eps: float = 1e-6, out_scale=None) -> None:
         arr[i].shift = _chk(shift, torch.float32, "shift").data_ptr()
         arr[i].scale = _chk(scale, torch.float32, "scale").data_ptr()
     if fp8:
-        L.check(lib.ca_ln_modulate_fp8(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), out_scale.data_ptr(),
-                                       x.shape[0], x.shape[1], arr, len(segments), eps, _stream()),
-                "ca_ln_modulate_fp8")
+        fn = lib.ca_ln_modulate_f32in_fp8 if x32 else lib.ca_ln_modulate_fp8
+        L.check(fn(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), out_scale.data_ptr(),
+                   x.shape[0], x.shape[1], arr, len(segments), eps, _stream()), "ca_ln_modulate_fp8")
         return
-    L.check(lib.ca_ln_modulate_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
-                                    arr, len(segments), eps, _stream()), "ca_ln_modulate_bf16")
+    fn = lib.ca_ln_modulate_f32in if x32 else lib.ca_ln_modulate_bf16
+    L.check(fn(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+               arr, len(segments), eps, _stream()), "ca_ln_modulate_bf16")
 
 
 def quantize_rows_fp8(x, out=None, out_scale=None):

@@ -147,7 +147,8 @@ class ConceptAttentionFluxPipeline:
         n_streams = max(1, min(n_streams, len(items)))
         while len(self._replicas) < n_streams:
             self._replicas.append(HipFluxDiT(self.params, self.device, weights=self.model.weights,
-                                             precision=self.model.precision)
+                                             precision=self.model.precision,
+                                             residual_dtype=self.model.residual_dtype)
                                   .set_precision(self.model.precision, self.model.keep_bf16_layers))
         while len(self._streams) < n_streams:
             self._streams.append(torch.cuda.Stream(device=self.device))
@@ -373,7 +374,8 @@ class ConceptAttentionFluxPipeline:
         n_streams = max(1, min(n_streams, len(items)))
         while len(self._replicas) < n_streams:
             self._replicas.append(HipFluxDiT(self.params, self.device, weights=self.model.weights,
-                                             precision=self.model.precision)
+                                             precision=self.model.precision,
+                                             residual_dtype=self.model.residual_dtype)
                                   .set_precision(self.model.precision, self.model.keep_bf16_layers))
         while len(self._streams) < n_streams:
             self._streams.append(torch.cuda.Stream(device=self.device))

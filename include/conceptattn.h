@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CA_VERSION 100 /* 0.1.0 */
+#define CA_VERSION 110 /* 0.1.1: ca_gemm_problem.out_f32, fp32-input LayerNorm, sparse heat-map norms */
 
 #define CA_OK 0
 #define CA_ERR_ARG (-1)    /* bad shape / null pointer / misalignment */
@@ -94,6 +94,10 @@ typedef struct {
   int32_t gate_rows;
   int32_t epilogue;  /* CA_EPI_* */
   int32_t ldp;       /* row stride of q_prerope */
+  int32_t out_f32;   /* 1: `out` (and `resid`) hold fp32 elements (ldc/ldr still in elements, % 4 == 0); BIAS and
+                        GATE_RESIDUAL only.  The fp32 residual stream: img_in / txt_in write it, the attention-
+                        and MLP-output projections update it in place; 0: bf16 as above */
+  int32_t _pad;
 } ca_gemm_problem;
 
 int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile, ca_stream_t stream);
@@ -150,6 +154,12 @@ typedef struct {
 
 int ca_ln_modulate_bf16(const void *x, int32_t ldx, void *out, int32_t ldo, int32_t M, int32_t H,
                         const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream);
+/* The same two with an fp32 input x (row stride ldx elements, % 4 == 0): the residual stream kept in fp32
+ * (its per-block bf16 rounding is what makes the heat-map error grow with depth). */
+int ca_ln_modulate_f32in(const float *x, int32_t ldx, void *out, int32_t ldo, int32_t M, int32_t H,
+                         const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream);
+int ca_ln_modulate_f32in_fp8(const float *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale, int32_t M,
+                             int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream);
 /* Same, with the result quantised for ca_gemm_fp8: out8 = e4m3 bytes (row stride ldo bytes, % 16),
  * out_scale[row] = absmax(row) / 448 (fp32 [M]). */
 int ca_ln_modulate_fp8(const void *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale, int32_t M,

@@ -278,3 +278,81 @@ def test_timestep_indices_are_validated_like_fancy_indexing():
     last = pipe.generate_image(timesteps=[1], **kw)
     neg = pipe.generate_image(timesteps=[-1], **kw)        # negative indices count from the end
     assert np.array_equal(last.concept_heatmaps, neg.concept_heatmaps)
+
+
+# ------------------------------------------------------------------ fp32 residual stream (kernels)
+@pytest.mark.parametrize("tile", [_lib.TILE_PP_256x256, _lib.TILE_PP_256x192, _lib.TILE_PP_256x128, _lib.TILE_256x64])
+@pytest.mark.parametrize("M", [260, 1000])
+def test_gemm_fp32_output_bias_and_gate_residual(tile, M):
+    """out_f32: img_in / txt_in write the fp32 residual stream (BIAS), proj / mlp.2 / linear2 update it in place
+    (GATE_RESIDUAL with two gate vectors); compared with an fp64 evaluation of the same bf16 operands."""
+    g = torch.Generator().manual_seed(M + tile)
+    N, K = 768, 512
+    a = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    b = torch.randn(N, generator=g).to(DEV, torch.bfloat16)
+    prod = a.double() @ w.double().T + b.double()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm([ops.Gemm(a, w, b, out)], tile)
+    assert (out.double() - prod).abs().max().item() < 1e-4 * prod.abs().max().item()      # fp32 accumulate, no rounding
+    x = torch.randn(M, N, generator=g).to(DEV)                                             # fp32 residual
+    g1, g2 = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    want = x.double().clone()
+    want[:4] += g1.double() * prod[:4]
+    want[4:] += g2.double() * prod[4:]
+    ops.gemm([ops.Gemm(a, w, b, x, _lib.EPI_GATE_RESIDUAL, resid=x, gate=g1, gate2=g2, gate_rows=4)], tile)
+    assert (x.double() - want).abs().max().item() < 1e-4 * want.abs().max().item()
+    # strided fp32 output (a row slice of a wider buffer) and rejection of the epilogues that have no fp32 form
+    wide = torch.zeros(M, N + 64, device=DEV)
+    ops.gemm([ops.Gemm(a, w, b, wide[:, 32:32 + N])], tile)
+    assert torch.equal(wide[:, 32:32 + N], out) and wide[:, :32].abs().max() == 0
+    with pytest.raises(ValueError):
+        ops.gemm([ops.Gemm(a, w, b, out, _lib.EPI_GELU_TANH)], tile)
+
+
+def test_ln_modulate_fp32_input_matches_bf16_input_on_representable_rows():
+    g = torch.Generator().manual_seed(5)
+    M, H = 777, 3072
+    xb = torch.randn(M, H, generator=g).to(DEV, torch.bfloat16)
+    sh, sc = torch.randn(H, generator=g).to(DEV), torch.randn(H, generator=g).to(DEV) * 0.2
+    sh2, sc2 = torch.randn(H, generator=g).to(DEV), torch.randn(H, generator=g).to(DEV) * 0.2
+    segs = [(100, sh, sc), (M, sh2, sc2)]
+    o16, o32 = torch.empty(M, H, device=DEV, dtype=torch.bfloat16), torch.empty(M, H, device=DEV, dtype=torch.bfloat16)
+    ops.ln_modulate(xb, o16, segs)
+    ops.ln_modulate(xb.float(), o32, segs)
+    assert torch.equal(o16, o32)              # same values in, same arithmetic
+    # genuinely fp32 rows against the oracle's formula
+    xf = torch.randn(M, H, generator=g).to(DEV) * 3 + 0.1234567
+    ops.ln_modulate(xf, o32, segs)
+    mu, var = xf.double().mean(-1, keepdim=True), xf.double().var(-1, unbiased=False, keepdim=True)
+    ln = (xf.double() - mu) / torch.sqrt(var + 1e-6)
+    want = torch.cat(((1 + sc.double()) * ln[:100] + sh.double(), (1 + sc2.double()) * ln[100:] + sh2.double()))
+    assert (o32.double() - want).abs().max().item() < 2 ** -7 * want.abs().max().item()
+    # fp8 output from an fp32 input: identical bytes / scales to the bf16-input kernel on representable rows
+    q16, s16 = torch.empty(M, H, device=DEV, dtype=torch.uint8), torch.empty(M, device=DEV)
+    q32, s32 = torch.empty(M, H, device=DEV, dtype=torch.uint8), torch.empty(M, device=DEV)
+    ops.ln_modulate(xb, q16, segs, out_scale=s16)
+    ops.ln_modulate(xb.float(), q32, segs, out_scale=s32)
+    assert torch.equal(q16, q32) and torch.equal(s16, s32)
+
+
+def test_fp32_residual_is_closer_to_the_oracle_than_bf16_residual():
+    """Tiny model, 2 + 2 blocks: both layouts run the same kernels; the fp32 stream must not be further from the
+    fp32 oracle than the bf16 one on `pred`, and both stay within the model test's bounds."""
+    p = tiny_params()
+    sd = {k: v.bfloat16().float() for k, v in synthetic_state_dict(p, seed=1).items()}
+    inp = {k: (v.bfloat16().float() if v.is_floating_point() else v)
+           for k, v in synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=3, seed=2).items()}
+    pred_o, _ = O.dit_forward(sd, p, O.patchify(inp["latent"]), inp["img_ids"], inp["txt"], inp["txt_ids"],
+                              inp["concepts"], inp["concept_ids"], inp["concept_vec"], torch.tensor([0.75]), inp["vec"])
+    errs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = HipFluxDiT(p, DEV, residual_dtype=dt)
+        m.load_state_dict(sd)
+        d = {k: v.to(DEV) for k, v in inp.items()}
+        pred, _ = m(img=O.patchify(inp["latent"]).to(DEV), img_ids=d["img_ids"], txt=d["txt"], txt_ids=d["txt_ids"],
+                    concepts=d["concepts"], concept_ids=d["concept_ids"], concept_vec=d["concept_vec"], y=d["vec"],
+                    timesteps=torch.tensor([0.75], device=DEV))
+        assert m.X.dtype == dt
+        errs[dt] = (pred.float().cpu() - pred_o).pow(2).mean().sqrt().item()
+    assert errs[torch.float32] <= errs[torch.bfloat16] * 1.05, errs
