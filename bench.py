@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--precision", choices=("bf16", "fp8"), default="bf16",
                     help="fp8: the large projections run on e4m3 operands (reduced-precision mode of "
                          "BASELINE.json configs[4]; NOT the headline metric, which is bf16)")
+    ap.add_argument("--residual", choices=("fp32", "bf16"), default="fp32",
+                    help="storage type of the residual streams (fp32 = the product default; bf16 = the reference's "
+                         "activation dtype, an A/B aid: see DESIGN.md section 2 for what it costs in heat-map error)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-launch HIP-event timing of the GEMM kernel (roofline.achieved then "
@@ -181,7 +184,8 @@ def main():
     C, T = args.concepts, T5_TOKENS[args.model]
     Lp = (args.size // 16) ** 2
     pipe = ConceptAttentionFluxPipeline(args.model, device=dev, weights="synthetic", weight_seed=0,
-                                        precision=args.precision)
+                                        precision=args.precision,
+                                        residual_dtype=torch.float32 if args.residual == "fp32" else torch.bfloat16)
     layer_indices = list(range(15, 19))
     n_timed = world * args.steps  # timed work items 0..n_timed-1, item i on rank i % world
 
@@ -368,7 +372,7 @@ def main():
                                    "(generate_image-equivalent call; random-init weights, synthetic latents/embeddings)",
                        "calls_per_step_per_gpu": 1, "heatmap_layers": layer_indices,
                        "tflop_per_call": flops_call / 1e12, "parallelism": f"replica x{world} (work items round-robin)",
-                       "streams_per_gpu": args.streams,
+                       "streams_per_gpu": args.streams, "residual_stream": args.residual,
                        **({"fp8_scope": "qkv/proj/mlp/linear1/linear2 of all blocks except double blocks "
                                         f"{layer_indices} (the heat-map layers stay bf16)"} if fp8 else {})},
             "calls_per_s": calls / elapsed,

@@ -22,13 +22,15 @@ from .params import T5_TOKENS, configs
 
 
 def load_flow_model(name: str, device="cuda", hf_download: bool = True, attention_block_class=None,
-                    dit_class=HipFluxDiT, weights="synthetic", weight_seed: int = 0, params=None):
+                    dit_class=HipFluxDiT, weights="synthetic", weight_seed: int = 0, params=None,
+                    residual_dtype=torch.float32):
     """Counterpart of load_flow_model (image_generator.py:19-47): builds ``dit_class(params)`` and fills
     it from ``weights``: "synthetic", a flux1-*.safetensors path (env FLUX_SCHNELL / FLUX_DEV are honoured
     like flux/util.py:33,65), or a state dict.  Nothing is downloaded."""
     import os
     p = params if params is not None else configs[name]
-    model = dit_class(p, device) if dit_class is HipFluxDiT else dit_class(p, attention_block_class=attention_block_class)
+    model = (dit_class(p, device, residual_dtype=residual_dtype) if dit_class is HipFluxDiT
+             else dit_class(p, attention_block_class=attention_block_class))
     env = {"flux-schnell": "FLUX_SCHNELL", "flux-dev": "FLUX_DEV"}.get(name)
     if isinstance(weights, str) and weights == "synthetic" and env and os.getenv(env):
         weights = os.getenv(env)
@@ -45,7 +47,7 @@ def load_flow_model(name: str, device="cuda", hf_download: bool = True, attentio
 class FluxGenerator:
     def __init__(self, model_name: str, device, offload: bool = False, attention_block_class=None,
                  dit_class=HipFluxDiT, weights="synthetic", weight_seed: int = 0, text_encoder=None,
-                 autoencoder=None, params=None, n_text_tokens=None):
+                 autoencoder=None, params=None, n_text_tokens=None, residual_dtype=torch.float32):
         from .pipeline import SyntheticTextEncoder
         self.device = torch.device(device)
         self.offload = offload
@@ -54,7 +56,7 @@ class FluxGenerator:
         self.params = params if params is not None else configs[model_name]
         self.model = load_flow_model(model_name, self.device, attention_block_class=attention_block_class,
                                      dit_class=dit_class, weights=weights, weight_seed=weight_seed,
-                                     params=self.params)
+                                     params=self.params, residual_dtype=residual_dtype)
         n_tok = n_text_tokens or T5_TOKENS.get(model_name, 256)
         enc = text_encoder or SyntheticTextEncoder(n_tok, self.params.context_in_dim, self.params.vec_in_dim,
                                                    self.device)

@@ -69,10 +69,12 @@ def colorize_heatmaps(heatmaps: np.ndarray, cmap: str = "plasma") -> list:
 class ConceptAttentionFluxPipeline:
     def __init__(self, model_name: str = "flux-schnell", offload_model: bool = False, device="cuda:0",
                  weights="synthetic", weight_seed: int = 0, text_encoder=None, autoencoder=None,
-                 params=None, n_text_tokens: Optional[int] = None, precision: str = "bf16"):
+                 params=None, n_text_tokens: Optional[int] = None, precision: str = "bf16",
+                 residual_dtype=torch.float32):
         """model_name / offload_model / device as in the reference (:100-113).  ``weights`` is
         "synthetic" (seeded random init), a path to a flux1-*.safetensors file, or a state dict.
-        ``precision="fp8"`` runs the large projections on e4m3 operands (HipFluxDiT.set_precision)."""
+        ``precision="fp8"`` runs the large projections on e4m3 operands (HipFluxDiT.set_precision);
+        ``residual_dtype`` is the storage type of the residual streams (fp32 by default, HipFluxDiT.__init__)."""
         if params is None and model_name not in configs:
             raise KeyError(model_name)
         self.model_name = model_name
@@ -85,7 +87,7 @@ class ConceptAttentionFluxPipeline:
         self.flux_generator = FluxGenerator(model_name=model_name, offload=offload_model, device=self.device,
                                             weights=weights, weight_seed=weight_seed, text_encoder=text_encoder,
                                             autoencoder=autoencoder, params=self.params,
-                                            n_text_tokens=n_text_tokens)
+                                            n_text_tokens=n_text_tokens, residual_dtype=residual_dtype)
         self.model = self.flux_generator.model
         self.model.set_precision(precision)
         self.fp8_keep_heatmap_layers = True  # generate path only; the sweeps/encode path run every block in fp8
