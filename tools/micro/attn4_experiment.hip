@@ -1,3 +1,8 @@
+// EXPERIMENT (round 2, not built into the library): ca_attn.hip with an added one-wave-per-SIMD kernel
+// (ca_attn4_kernel: 4 waves x 64 rows, exponentials of one 32-row block in the MFMA gaps of the other; selected with
+// CA_ATTN_KERNEL=4).  Correct (all attention tests pass) but 420 us vs 253 us for 4352x4352x24 heads from plain HIP:
+// hipcc keeps the score accumulators in AGPRs (one v_accvgpr_read per exponential), issues every fragment read right
+// before its MFMA (lgkmcnt(0) per MFMA) and does not follow the requested MFMA/VALU interleave.  Kept for the record.
 // Flash-attention forward for gfx950 (MI355X), head_dim 128, bf16 in/out, fp32 softmax state.
 //
 // One workgroup = 8 waves = 256 query rows of one head (32 rows per wave, Q fragments in
@@ -323,6 +328,346 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 }
 
 
+// =============================================================================================
+// Four-wave variant: one workgroup = 4 waves = 256 query rows, ONE wave per SIMD, 64 rows (two 32-row blocks A, B)
+// per wave, and the whole 512-register file per wave.
+//
+// Why (measured on the 8-wave kernel above): with two waves per SIMD running the same program in lockstep, both
+// are in their MFMA phases together and in their softmax phases together, so the matrix pipe idles during the
+// softmax (45 % busy on occupied CUs).  Here a wave owns its SIMD and overlaps the two kinds of work itself:
+//     QK_A | QK_B + softmax_A | PV_A + softmax_B | PV_B
+// -- the exponentials of one block are issued in the gaps of the other block's MFMAs (sched_group_barrier pins
+// the interleave: one MFMA, then a slice of vector instructions).  Same LDS ring (tile t+1 staged by LDS-DMA at
+// the top of iteration t, one vmcnt(0) + barrier at its end), LDS images, swizzles and MFMA operand maps as above;
+// K / V fragments are read per use (16 bytes x 64 lanes feed one MFMA), not kept: registers are the scarcer thing.
+// The softmax reference is set by the first tile and then kept (see tile_body above): a row sum above
+// REDO_LIMIT sends that block through a max-tracking redo of the tile.
+// Waves with fewer than two valid 32-row blocks (ragged last query block, the C concept rows) take the simple
+// one-block path or only help staging; every wave passes the same barriers.
+#define CA_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SGB_MFMA = 0x8, SGB_VALU = 0x2, SGB_TRANS = 0x400, SGB_DSR = 0x100;
+
+__global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int bid = blockIdx.x;
+  const int prob = bid < L.blocks_p1 ? 1 : 0;
+  if (!prob) bid -= L.blocks_p1;
+  const int nqb = L.nqb[prob];
+  const int xg = bid & 7, idx = bid >> 3;
+  const int head = xg + 8 * (idx / nqb);
+  const int qb = idx % nqb;
+  if (head >= L.num_heads) return;
+  const ca_attn_problem &P = L.p[prob];
+  const int nq = P.nq, n0 = P.n0, nkeys = P.n0 + P.n1;
+  const int ldkv = P.ldkv;
+
+  const int h = lane >> 5, ql = lane & 31;
+  const int qrow0 = qb * 256 + wave * 64;
+  // blocks of this wave that hold at least one valid query row (wave-uniform): 0, 1 or 2
+  const int nblk = qrow0 >= nq ? 0 : (qrow0 + 32 >= nq ? 1 : 2);
+
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int qrow = min(qrow0 + 32 * b + ql, nq - 1);
+    const bf16 *qp = (const bf16 *)P.q + (size_t)qrow * P.ldq + head * 128 + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[b][ks] = *(const bf16x8 *)(qp + ks * 16);
+  }
+
+  // ---- staging: 16 one-KiB pieces per matrix and tile, 4 per wave
+  const int st_row = lane >> 4, st_cp = lane & 15;
+  const bf16 *k0p = (const bf16 *)P.k0 + head * 128;
+  const bf16 *v0p = (const bf16 *)P.v0 + head * 128;
+  const bf16 *k1p = (const bf16 *)P.k1 + head * 128;
+  const bf16 *v1p = (const bf16 *)P.v1 + head * 128;
+  uint32_t koff[4], voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 4 * (wave * 4 + j) + st_row;
+    koff[j] = ((uint32_t)r * (uint32_t)ldkv + ((st_cp ^ (r & 15)) << 3)) * 2u;
+    voff[j] = ((uint32_t)r * (uint32_t)ldkv + ((st_cp ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 3)) * 2u;
+  }
+  const int nt = (nkeys + KV_TILE - 1) / KV_TILE;
+  auto stage_tile = [&](int tile, int buf) {
+    char *kb = smem + buf * BUF_BYTES;
+    const int lo = tile * KV_TILE;
+    const bool in0 = lo + KV_TILE <= n0, in1 = lo >= n0 && lo + KV_TILE <= nkeys;
+    if (in0 || in1) {  // all 64 rows in one segment: scalar tile base + lane constant
+      const size_t ro = (size_t)(in0 ? lo : lo - n0) * ldkv;
+      const bf16 *kt = (in0 ? k0p : k1p) + ro, *vt = (in0 ? v0p : v1p) + ro;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = wave * 4 + j;
+        ca_glds16_asm_s(kt, koff[j], kb + q * 1024);
+        ca_glds16_asm_s(vt, voff[j], kb + TILE_BYTES + q * 1024);
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = wave * 4 + j;
+      const int r = 4 * q + st_row;
+      const int kk = min(lo + r, nkeys - 1);
+      const bool s0 = kk < n0;
+      const size_t ro = (size_t)(s0 ? kk : kk - n0) * ldkv;
+      ca_glds16_asm((s0 ? k0p : k1p) + ro + ((st_cp ^ (r & 15)) << 3), kb + q * 1024);
+      ca_glds16_asm((s0 ? v0p : v1p) + ro + ((st_cp ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 3),
+                    kb + TILE_BYTES + q * 1024);
+    }
+  };
+
+  // ---- fragment read offsets (as in the 8-wave kernel)
+  const int k_lane = ql * 256 + (((h ^ (ql & 15)) & 15) << 4);
+  const int qq = (lane & 15) >> 2;
+  const int c_lane = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+  int v_lane[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int x = (qq << 2) | ((2 * jj + h) & 3);
+    v_lane[jj] = (4 * h + qq) * 256 + (((c_lane ^ x) & 15) << 4) + 8 * (lane & 1);
+  }
+
+  f32x16 o[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][db][r] = 0.f;
+  float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+  const float sl2 = L.scale_log2;
+
+  const bool ragged = (nkeys & (KV_TILE - 1)) != 0;
+  const int nt_full = ragged ? nt - 1 : nt;
+
+  auto body = [&](int t, auto cur_tag, auto init_tag) {
+    constexpr int cur = decltype(cur_tag)::value;
+    constexpr bool INIT = decltype(init_tag)::value;
+    const char *kbuf = smem + cur * BUF_BYTES;
+    const char *vbuf = kbuf + TILE_BYTES;
+    auto read_kf = [&](int kb, int ks) { return *(const bf16x8 *)(kbuf + kb * 8192 + (k_lane ^ (ks << 5))); };
+    auto read_vf = [&](int kb, int sk, int db) {
+      const char *vrow = vbuf + (32 * kb + 16 * sk) * 256;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4 *)(vrow + (v_lane[0] ^ (db << 6))));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4 *)(vrow + 8 * 256 + (v_lane[1] ^ (db << 6))));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto qk = [&](auto b_tag, f32x16 (&s)[2]) {
+      constexpr int b = decltype(b_tag)::value;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_kf(kb, ks), qf[b][ks], s[kb], 0, 0, 0);
+      }
+    };
+    // classical step for block b on scores s: raise the reference to the tile maximum (rescaling O^T and l when
+    // it moves), exponentiate; returns the row sum.  masked: keys past nkeys count as -inf.
+    auto softmax_max = [&](auto b_tag, f32x16 (&s)[2], bool masked) {
+      constexpr int b = decltype(b_tag)::value;
+      if (masked) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KV_TILE + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key >= nkeys) s[kb][r] = -INFINITY;
+          }
+      }
+      float mx = s[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
+      if (__builtin_amdgcn_ballot_w64(mx > m_run[b]) != 0) {
+        const float m_new = fmaxf(m_run[b], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+        m_run[b] = m_new;
+        l_run[b] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[b][db][r] *= alpha;
+      }
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_run[b]));
+          s[kb][r] = p;
+          rs += p;
+        }
+      return rs;
+    };
+    auto pv = [&](auto b_tag, const f32x16 (&s)[2]) {
+      constexpr int b = decltype(b_tag)::value;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+          const bf16x8 pf = pack8(s[kb], 8 * sk);
+#pragma unroll
+          for (int db = 0; db < 4; ++db)
+            o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_vf(kb, sk, db), pf, o[b][db], 0, 0, 0);
+        }
+    };
+    using BA = std::integral_constant<int, 0>;
+    using BB = std::integral_constant<int, 1>;
+    const bool masked = t >= nt_full;
+    auto mask_keys = [&](f32x16 (&s)[2]) {  // ragged last tile: keys past nkeys count as -inf
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KV_TILE + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (key >= nkeys) s[kb][r] = -INFINITY;
+        }
+    };
+    if (INIT) {
+      // reference of every row := the row maximum over tile 0 (scores only; O^T and l are not touched, and the
+      // loop below then treats tile 0 like any other tile)
+      f32x16 s[2];
+      qk(BA{}, s);
+      if (masked) mask_keys(s);
+      float mx = s[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+      m_run[0] = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
+      qk(BB{}, s);
+      if (masked) mask_keys(s);
+      mx = s[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+      m_run[1] = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
+      return;
+    }
+    // ---- one tile, both blocks: QK_A | QK_B + exp_A | PV_A + exp_B | PV_B
+    f32x16 sa[2], sb[2];
+    float rsa = 0.f, rsb = 0.f;
+    qk(BA{}, sa);
+    if (masked) mask_keys(sa);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sb[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        sb[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_kf(kb, ks), qf[1][ks], sb[kb], 0, 0, 0);
+#pragma unroll
+        for (int e = 2 * (kb * 8 + ks); e < 2 * (kb * 8 + ks) + 2; ++e) {  // two of block A's 32 scores per gap
+          const float p = __builtin_amdgcn_exp2f(fmaf(sa[e >> 4][e & 15], sl2, -m_run[0]));
+          sa[e >> 4][e & 15] = p;
+          rsa += p;
+        }
+        CA_SGB(SGB_DSR, 1);
+        CA_SGB(SGB_MFMA, 1);
+        CA_SGB(SGB_VALU, 4);
+        CA_SGB(SGB_TRANS, 2);
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(!(rsa <= REDO_LIMIT)) != 0) {  // rare: redo block A with a raised reference
+      qk(BA{}, sa);
+      rsa = softmax_max(BA{}, sa, masked);
+    }
+    l_run[0] += rsa;
+    if (masked) mask_keys(sb);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const bf16x8 pf = pack8(sa[kb], 8 * sk);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_vf(kb, sk, db), pf, o[0][db], 0, 0, 0);
+#pragma unroll
+          for (int e = 2 * ((kb * 2 + sk) * 4 + db); e < 2 * ((kb * 2 + sk) * 4 + db) + 2; ++e) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sb[e >> 4][e & 15], sl2, -m_run[1]));
+            sb[e >> 4][e & 15] = p;
+            rsb += p;
+          }
+          CA_SGB(SGB_DSR, 2);
+          CA_SGB(SGB_MFMA, 1);
+          CA_SGB(SGB_VALU, 4);
+          CA_SGB(SGB_TRANS, 2);
+        }
+      }
+    if (__builtin_amdgcn_ballot_w64(!(rsb <= REDO_LIMIT)) != 0) {
+      qk(BB{}, sb);
+      rsb = softmax_max(BB{}, sb, masked);
+    }
+    l_run[1] += rsb;
+    pv(BB{}, sb);
+  };
+
+  stage_tile(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): also covers the Q loads for hipcc's bookkeeping
+  __syncthreads();
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  // Waves with one valid block run both (block B then repeats the last valid row; its results are dropped);
+  // waves with none only stage.  One code path for O^T keeps it in the accumulator registers throughout.
+  if (nblk > 0) body(0, B0{}, std::true_type{});
+  for (int t = 0; t < nt; t += 2) {
+    if (t + 1 < nt) stage_tile(t + 1, 1);
+    if (nblk > 0) body(t, B0{}, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 >= nt) break;
+    if (t + 2 < nt) stage_tile(t + 2, 0);
+    if (nblk > 0) body(t + 1, B1{}, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue, per block: O[q][d] = O^T[d][q] / l
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    if (b >= nblk) break;
+    const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32);
+    const float inv = 1.0f / l_tot;
+    const int row = qrow0 + 32 * b + ql;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    bf16 *op = (bf16 *)P.out + (size_t)min(row, nq - 1) * P.ldo + head * 128 + 8 * h;
+    const bool row_ok = row < nq;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const uint32_t ax = ca_pack2(o[b][db][4 * g] * inv, o[b][db][4 * g + 1] * inv);
+        const uint32_t ay = ca_pack2(o[b][db][4 * g + 2] * inv, o[b][db][4 * g + 3] * inv);
+        const uint32_t bx = ca_pack2(o[b][db][4 * g + 4] * inv, o[b][db][4 * g + 5] * inv);
+        const uint32_t by = ca_pack2(o[b][db][4 * g + 6] * inv, o[b][db][4 * g + 7] * inv);
+        const u32x2 sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        const u32x2 sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        if (row_ok) *(uint4 *)(op + 32 * db + 8 * g) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      }
+    if (row_ok && P.out_f32) {
+      float *fp = P.out_f32 + (size_t)row * P.ldo32 + head * 128 + 4 * h;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(f32x4 *)(fp + 32 * db + 8 * g) = f32x4{o[b][db][4 * g] * inv, o[b][db][4 * g + 1] * inv,
+                                                  o[b][db][4 * g + 2] * inv, o[b][db][4 * g + 3] * inv};
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
@@ -337,7 +682,9 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   // ~200 vector instructions of softmax, and a vector wave next to a saturated MFMA wave on the same SIMD
   // runs at only ~47 % of its solo speed.  A two-group ping-pong schedule of the same tiles was slower
   // (350 us) and is not kept.
-  static const int nw = (getenv("CA_ATTN_WAVES") && atoi(getenv("CA_ATTN_WAVES")) == 4) ? 4 : 8;
+  // CA_ATTN_KERNEL=4 selects ca_attn4_kernel (one wave per SIMD, 64 rows per wave); default: the 8-wave kernel
+  static const int a4 = (getenv("CA_ATTN_KERNEL") && atoi(getenv("CA_ATTN_KERNEL")) == 4) ? 1 : 0;
+  static const int nw = (getenv("CA_ATTN_WAVES") && atoi(getenv("CA_ATTN_WAVES")) == 4 && !a4) ? 4 : 8;
   const int qrows = nw * 32;
   AttnLaunch L = {};
   L.num_heads = num_heads;
@@ -386,13 +733,17 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
                                        ATTN_LDS);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)ca_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)ca_attn4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
     if (e != hipSuccess) {
       ca_set_error("ca_attn_fwd_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
     attr_done.fetch_or(dev_bit, std::memory_order_release);  // idempotent: a race only repeats the call
   }
-  if (nw == 8)
+  if (a4)
+    hipLaunchKernelGGL(ca_attn4_kernel, dim3(total), dim3(256), ATTN_LDS, (hipStream_t)stream, L);
+  else if (nw == 8)
     hipLaunchKernelGGL(ca_attn_kernel<8>, dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
   else
     hipLaunchKernelGGL(ca_attn_kernel<4>, dim3(total), dim3(256), ATTN_LDS, (hipStream_t)stream, L);

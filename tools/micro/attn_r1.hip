@@ -36,7 +36,7 @@ struct AttnLaunch {
 };
 
 constexpr int KV_TILE = 64;
-constexpr float REDO_LIMIT = 1073741824.0f;  // 2^30: a row sum above this sends the tile through the max-tracking path
+constexpr float RESCALE_LOG2 = 8.0f;  // deferred-rescale threshold of the online softmax, in log2 units
 constexpr int TILE_BYTES = KV_TILE * 256;  // one K or V tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;
 constexpr int ATTN_LDS = 2 * BUF_BYTES;
@@ -163,76 +163,62 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
   // loop's code (hipcc otherwise turns the uniform test into 32 v_cndmask per tile for every tile).
   // The LDS buffer index is a compile-time constant (tile t lives in buffer t & 1, the loop is unrolled by two),
   // so every fragment address is a loop-invariant lane register plus an instruction immediate.
-  auto tile_body = [&](int t, auto cur_tag, auto masked_tag, auto first_tag) {
+  auto tile_body = [&](int t, auto cur_tag, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    constexpr bool FIRST = decltype(first_tag)::value;  // tile 0: the reference is still unset
     constexpr int cur = decltype(cur_tag)::value;
     const char *kbuf = smem + cur * BUF_BYTES;
     const char *vbuf = kbuf + TILE_BYTES;
-    // ---- S^T[key][q] = sum_d K[key][d] Q[q][d], then p = exp2(s * scale - m_run).
-    // The running reference m_run of a row is NOT the running maximum: softmax is invariant to the reference,
-    // and fp32 sums / bf16 P fragments keep their relative precision at any scale, so the reference only has to
-    // keep 2^(s - m_run) inside the exponent range.  The first tile sets it to the tile's row maximum; after that
-    // a tile is exponentiated against the stale reference WITHOUT computing its maximum (23 max + a shuffle +
-    // compare per tile saved: the loop is vector-issue bound), and only if a row sum comes out above 2^30 (some
-    // score more than ~30 octaves above the reference: rare after the first tile) the tile is redone the classical
-    // way: S recomputed, reference raised to the new maximum, O^T and l rescaled.  Nothing of the tile has been
-    // added to l or O^T at that point, so everything at the old reference is rescaled exactly once.
+    // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
     f32x16 s[2];
-    float rs;
-    bool with_max = FIRST;
-#pragma nounroll
-    for (;;) {
-      asm volatile("" ::: "memory");  // the K fragments are re-read per pass (hoisted, they would pin 64 VGPRs)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const bf16x8 kf = *(const bf16x8 *)(kbuf + kb * 8192 + (k_lane ^ (ks << 5)));
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-        }
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 kf = *(const bf16x8 *)(kbuf + kb * 8192 + (k_lane ^ (ks << 5)));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
       }
-      if constexpr (MASKED) {  // key = 64*t + 32*kb + (r&3) + 8*(r>>2) + 4*h
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = t * KV_TILE + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (key >= nkeys) s[kb][r] = -INFINITY;
-          }
-      }
-      if (with_max) {  // wave-uniform
-        // this lane: query row ql, 32 of the tile's 64 keys; lane^32 has the rest
-        float mx = s[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-      }
-      rs = 0.f;
+    }
+    if constexpr (MASKED) {  // key = 64*t + 32*kb + (r&3) + 8*(r>>2) + 4*h
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_run));
-          s[kb][r] = p;
-          rs += p;
+          const int key = t * KV_TILE + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (key >= nkeys) s[kb][r] = -INFINITY;
         }
-      // (a row whose keys are all masked so far has m_run = -1e30 and rs = 0: not > the limit; inf compares true)
-      if (with_max || __builtin_amdgcn_ballot_w64(!(rs <= REDO_LIMIT)) == 0) break;
-      with_max = true;
     }
+    // ---- online softmax (this lane: query row ql, 32 of the tile's 64 keys; lane^32 has the rest)
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
+    // The reference maximum of a row is only raised (and O^T, l rescaled) when some row of the wave exceeds
+    // it by more than RESCALE_LOG2: until then p = exp2(s - m_run) is at most 2^RESCALE_LOG2 instead of 1,
+    // which fp32 sums and bf16 P fragments carry without loss, and O/l is unchanged.  After the first
+    // tiles this is rare: no 64 accumulator multiplies per tile.
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + RESCALE_LOG2) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_run));
+        s[kb][r] = p;
+        rs += p;
+      }
     l_run += rs;
     // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; P^T fragments straight from the S^T registers
 #pragma unroll
@@ -256,30 +242,24 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 
   const bool ragged = (nkeys & (KV_TILE - 1)) != 0;
   const int nt_full = ragged ? nt - 1 : nt;  // tiles the main loop handles (no key masking)
-  auto iteration = [&](int t, auto cur_tag, auto first_tag) {
+  auto iteration = [&](int t, auto cur_tag) {
     constexpr int cur = decltype(cur_tag)::value;
     if (t + 1 < nt) stage_tile(t + 1, cur ^ 1);
-    if (active) tile_body(t, cur_tag, std::false_type{}, first_tag);
+    if (active) tile_body(t, cur_tag, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed (this wave's pieces)
     __syncthreads();
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  const std::false_type later{};
   int t = 0;
-  if (nt_full > 0) {  // tile 0 sets the softmax reference of every row
-    iteration(0, B0{}, std::true_type{});
-    t = 1;
-  }
   for (; t + 1 < nt_full; t += 2) {
-    iteration(t, B1{}, later);
-    iteration(t + 1, B0{}, later);
+    iteration(t, B0{});
+    iteration(t + 1, B1{});
   }
-  if (t < nt_full) iteration(t, B1{}, later);
+  if (t < nt_full) iteration(t, B0{});
   if (ragged && active) {
-    if (nt == 1) tile_body(0, B0{}, std::true_type{}, std::true_type{});
-    else if ((nt - 1) & 1) tile_body(nt - 1, B1{}, std::true_type{}, later);
-    else tile_body(nt - 1, B0{}, std::true_type{}, later);
+    if ((nt - 1) & 1) tile_body(nt - 1, B1{}, std::true_type{});
+    else tile_body(nt - 1, B0{}, std::true_type{});
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ;  d = 32*db + (r&3) + 8*(r>>2) + 4*h
@@ -321,7 +301,6 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
     }
   }
 }
-
 
 }  // namespace
 
