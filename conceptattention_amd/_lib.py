@@ -17,8 +17,9 @@ TILE_AUTO, TILE_256x256, TILE_256x192, TILE_256x128, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_PP_256x256, TILE_PP_256x128, TILE_PP_256x192 = 5, 6, 7
 NORM_SOFTMAX, NORM_SPARSEMAX, NORM_ENTMAX15 = 0, 1, 2
 NORMS = {"softmax": NORM_SOFTMAX, "sparsemax": NORM_SPARSEMAX, "entmax15": NORM_ENTMAX15}
-MAX_SEGMENTS = 4
+MAX_SEGMENTS = 16
 GEMM_MAX_PROBLEMS = 2
+ATTN_MAX_PROBLEMS = 16
 
 
 class GemmProblem(C.Structure):
@@ -29,14 +30,17 @@ class GemmProblem(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("ld2", C.c_int32), ("n_split", C.c_int32), ("gate_rows", C.c_int32),
-                ("epilogue", C.c_int32), ("ldp", C.c_int32), ("out_f32", C.c_int32), ("_pad", C.c_int32)]
+                ("epilogue", C.c_int32), ("ldp", C.c_int32), ("out_f32", C.c_int32), ("gate_stride", C.c_int32),
+                ("gate_item_rows", C.c_int32), ("gate2_item_rows", C.c_int32)]
 
 
 class AttnProblem(C.Structure):
     _fields_ = [("q", C.c_void_p), ("out", C.c_void_p), ("k0", C.c_void_p), ("v0", C.c_void_p),
                 ("k1", C.c_void_p), ("v1", C.c_void_p), ("out_f32", C.c_void_p),
+                ("q1", C.c_void_p), ("out1", C.c_void_p),
                 ("nq", C.c_int32), ("n0", C.c_int32), ("n1", C.c_int32),
-                ("ldq", C.c_int32), ("ldo", C.c_int32), ("ldkv", C.c_int32), ("ldo32", C.c_int32)]
+                ("ldq", C.c_int32), ("ldo", C.c_int32), ("ldkv", C.c_int32), ("ldo32", C.c_int32),
+                ("nq0", C.c_int32), ("_pad", C.c_int32 * 3)]
 
 
 class ModSegment(C.Structure):

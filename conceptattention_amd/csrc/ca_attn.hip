@@ -28,10 +28,11 @@
 namespace {
 
 struct AttnLaunch {
-  ca_attn_problem p[2];
-  int32_t nqb[2];  // 256-row query blocks per head
+  ca_attn_problem p[CA_ATTN_MAX_PROBLEMS];
+  int32_t nqb[CA_ATTN_MAX_PROBLEMS];      // 256-row query blocks per head
+  int32_t blk_end[CA_ATTN_MAX_PROBLEMS];  // workgroups of problems 0..i (problems are laid out one after another)
+  int32_t n_problems;
   int32_t num_heads;
-  int32_t blocks_p1;  // workgroups of problem 1 (they come first in the grid)
   float scale_log2;   // softmax scale * log2(e)
 };
 
@@ -57,8 +58,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 
   // ---- which (problem, head, query block)
   int bid = blockIdx.x;
-  const int prob = bid < L.blocks_p1 ? 1 : 0;
-  if (!prob) bid -= L.blocks_p1;
+  int prob = 0;
+  while (prob + 1 < L.n_problems && bid >= L.blk_end[prob]) ++prob;  // scalar: a handful of problems per launch
+  if (prob) bid -= L.blk_end[prob - 1];
   const int nqb = L.nqb[prob];
   // heads are dealt to the 8 XCD groups (blockIdx % 8) so that a head's query blocks share an L2
   const int xg = bid & 7, idx = bid >> 3;
@@ -78,7 +80,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
   // ---- Q fragments (B operand: lane holds Q[q = lane&31][d = 16*ks + 8*h + j])
   bf16x8 qf[8];
   {
-    const bf16 *qp = (const bf16 *)P.q + (size_t)qrow * P.ldq + head * 128 + h * 8;
+    // query / output rows come in up to two row segments: rows [0, nq0) from q / out, the rest from q1 / out1
+    const bf16 *qp = (qrow < P.nq0 ? (const bf16 *)P.q + (size_t)qrow * P.ldq
+                                   : (const bf16 *)P.q1 + (size_t)(qrow - P.nq0) * P.ldq) + head * 128 + h * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8 *)(qp + ks * 16);
   }
@@ -293,7 +297,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
     // store is predicated on the row being valid.
     {
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-      bf16 *op = (bf16 *)P.out + (size_t)min(qrow0 + ql, nq - 1) * P.ldo + head * 128 + 8 * h;
+      const int orow = min(qrow0 + ql, nq - 1);
+      bf16 *op = (orow < P.nq0 ? (bf16 *)P.out + (size_t)orow * P.ldo : (bf16 *)P.out1 + (size_t)(orow - P.nq0) * P.ldo) +
+                 head * 128 + 8 * h;
       const bool row_ok = qrow0 + ql < nq;
 #pragma unroll
       for (int db = 0; db < 4; ++db)
@@ -327,20 +333,17 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 
 extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
                                 float scale, ca_stream_t stream) {
-  if (!problems || n_problems < 1 || n_problems > 2 || num_heads < 1) {
-    ca_set_error("ca_attn_fwd_bf16: n_problems=%d num_heads=%d", n_problems, num_heads);
+  if (!problems || n_problems < 1 || n_problems > CA_ATTN_MAX_PROBLEMS || num_heads < 1) {
+    ca_set_error("ca_attn_fwd_bf16: n_problems=%d (max %d) num_heads=%d", n_problems, CA_ATTN_MAX_PROBLEMS, num_heads);
     return CA_ERR_ARG;
   }
-  // Default: 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: ~258 us for
+  // Default: 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: ~250 us for
   // 4352x4352x24 heads on MI355X.  A/B aid (same numerics): CA_ATTN_WAVES=4 = 128-row workgroups.
-  // What bounds it (tools/micro/coissue.hip): per 64-key tile a wave issues 32 MFMAs (1024 cycles) and
-  // ~200 vector instructions of softmax, and a vector wave next to a saturated MFMA wave on the same SIMD
-  // runs at only ~47 % of its solo speed.  A two-group ping-pong schedule of the same tiles was slower
-  // (350 us) and is not kept.
   static const int nw = (getenv("CA_ATTN_WAVES") && atoi(getenv("CA_ATTN_WAVES")) == 4) ? 4 : 8;
   const int qrows = nw * 32;
   AttnLaunch L = {};
   L.num_heads = num_heads;
+  L.n_problems = n_problems;
   L.scale_log2 = scale * 1.4426950408889634f;
   const int hx = (num_heads + 7) / 8;  // heads per XCD group
   int total = 0;
@@ -348,6 +351,10 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
     const ca_attn_problem &p = problems[i];
     if (!p.q || !p.out || !p.k0 || !p.v0 || p.nq < 1 || p.n0 < 1 || p.n1 < 0 || (p.n1 > 0 && (!p.k1 || !p.v1))) {
       ca_set_error("ca_attn_fwd_bf16[%d]: null pointer or empty shape (nq=%d n0=%d n1=%d)", i, p.nq, p.n0, p.n1);
+      return CA_ERR_ARG;
+    }
+    if (p.nq0 < 0 || p.nq0 > p.nq || (p.nq0 > 0 && p.nq0 < p.nq && (!p.q1 || !p.out1 || p.out_f32))) {
+      ca_set_error("ca_attn_fwd_bf16[%d]: two query segments need 0 < nq0 < nq, q1 and out1 (and no out_f32)", i);
       return CA_ERR_ARG;
     }
     if (p.ldq % 8 || p.ldo % 8 || p.ldkv % 8 || p.ldq < num_heads * 128 || p.ldo < num_heads * 128 ||
@@ -360,7 +367,7 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
       return CA_ERR_ARG;
     }
     if (((uintptr_t)p.q | (uintptr_t)p.out | (uintptr_t)p.k0 | (uintptr_t)p.v0 | (uintptr_t)p.k1 |
-         (uintptr_t)p.v1 | (uintptr_t)p.out_f32) & 15) {
+         (uintptr_t)p.v1 | (uintptr_t)p.out_f32 | (uintptr_t)p.q1 | (uintptr_t)p.out1) & 15) {
       ca_set_error("ca_attn_fwd_bf16[%d]: pointers must be 16-byte aligned", i);
       return CA_ERR_ARG;
     }
@@ -369,15 +376,14 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
       L.p[i].k1 = p.k0;
       L.p[i].v1 = p.v0;
     }
+    if (p.nq0 == 0 || p.nq0 == p.nq) {  // one query segment (nq0 = 0 is the pre-batch spelling of "all rows in q")
+      L.p[i].nq0 = p.nq;
+      L.p[i].q1 = p.q;
+      L.p[i].out1 = p.out;
+    }
     L.nqb[i] = (p.nq + qrows - 1) / qrows;
     total += 8 * hx * L.nqb[i];
-  }
-  if (n_problems == 1) {
-    L.p[1] = L.p[0];
-    L.nqb[1] = 1;
-    L.blocks_p1 = 0;
-  } else {
-    L.blocks_p1 = 8 * hx * L.nqb[1];
+    L.blk_end[i] = total;
   }
   static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
   const unsigned long long dev_bit = ca_device_bit();

@@ -49,6 +49,20 @@ struct Cfg {
 
 constexpr int GROUP_M = 8;
 
+// Gate vector of output row m (GATE_RESIDUAL).  Rows < gate_rows use `gate`, the others `gate2` (or `gate` when
+// gate2 is NULL).  With gate_stride != 0 each of the two row ranges is a sequence of work items of
+// gate_item_rows / gate2_item_rows rows, and item i of a range uses its base vector + i * gate_stride floats
+// (batched forward: the items of a batch have their own adaLN gates).
+__device__ __forceinline__ const float *ca_gate_of(const ca_gemm_problem &P, int m) {
+  const bool first = m < P.gate_rows;
+  const float *g = (first || !P.gate2) ? P.gate : P.gate2;
+  if (P.gate_stride) {
+    const int r = first ? m : m - P.gate_rows;
+    g += (size_t)(r / (first ? P.gate_item_rows : P.gate2_item_rows)) * P.gate_stride;
+  }
+  return g;
+}
+
 template <int M_REP, int N_REP>
 __global__ __launch_bounds__(512, 2) void ca_gemm_kernel(const GemmLaunch L) {
   using C = Cfg<M_REP, N_REP>;
@@ -190,24 +204,21 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_kernel(const GemmLaunch L) {
 
   if (epi == CA_EPI_GATE_RESIDUAL) {
     float gate_a[4 * N_REP], gate_b[4 * N_REP];
-    const float *g1 = P.gate + nb;
-    const float *g2 = (P.gate2 ? P.gate2 : P.gate) + nb;
-#pragma unroll
-    for (int j = 0; j < N_REP; ++j) {
-      const f32x4 ga = *(const f32x4 *)(g1 + 4 * j);
-      const f32x4 gb = *(const f32x4 *)(g2 + 4 * j);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        gate_a[4 * j + r] = ga[r];
-        gate_b[4 * j + r] = gb[r];
-      }
-    }
     const char *resb = (const char *)P.resid;
 #pragma unroll
     for (int i = 0; i < M_REP; ++i) {
       const int m = mrow0 + 16 * i;
       if (m < M) {
-        const bool first = m < P.gate_rows;
+        {  // this row's gate vector (per row: a tile may span items and both row ranges)
+          const float *gr = ca_gate_of(P, m) + nb;
+#pragma unroll
+          for (int j = 0; j < N_REP; ++j) {
+            const f32x4 ga = *(const f32x4 *)(gr + 4 * j);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gate_a[4 * j + r] = gate_b[4 * j + r] = ga[r];
+          }
+        }
+        const bool first = true;
         if (P.out_f32) {  // fp32 residual stream: 16 bytes per 4 columns, read and written in place
           const f32x4 *rp = (const f32x4 *)(resb + ((size_t)m * P.ldr + nb) * 4);
           f32x4 *op = (f32x4 *)(outb + ((size_t)m * ldo + ncol) * 4);
@@ -648,19 +659,30 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
         for (int r = 0; r < 4; ++r) bias[4 * j + r] = (float)b4[r];
       }
     }
+    // Gates: the usual tile lies inside one work item and one row range, so its rows share ONE gate vector, loaded
+    // once (gate_a; `straddle` false).  A tile that spans items or the gate_rows boundary (the concept | text tile)
+    // fetches the vector per row fragment instead.
+    bool straddle = false;
     if (epi == CA_EPI_GATE_RESIDUAL) {
-      const float *g1 = P.gate + nb;
-      const float *g2 = (P.gate2 ? P.gate2 : P.gate) + nb;
+      const float *g_lo = ca_gate_of(P, m0), *g_hi = ca_gate_of(P, min(m0 + C::BM, M) - 1);
+      straddle = g_lo != g_hi;  // workgroup-uniform
+      const float *g1 = g_lo + nb;
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
-        const f32x4 ga = *(const f32x4 *)(g1 + 4 * j), gb = *(const f32x4 *)(g2 + 4 * j);
+        const f32x4 ga = *(const f32x4 *)(g1 + 4 * j);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          gate_a[4 * j + r] = ga[r];
-          gate_b[4 * j + r] = gb[r];
-        }
+        for (int r = 0; r < 4; ++r) gate_a[4 * j + r] = gate_b[4 * j + r] = ga[r];
       }
     }
+    auto row_gate = [&](int m) {  // straddling tile only: this lane's row m has its own vector
+      const float *gr = ca_gate_of(P, min(m, M - 1)) + nb;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const f32x4 ga = *(const f32x4 *)(gr + 4 * j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gate_a[4 * j + r] = ga[r];
+      }
+    };
     // the residual rows are fetched up front for all 8 row fragments (rows clamped, only the store is
     // predicated): one round trip to memory instead of eight dependent ones
     if (P.out_f32 && (epi == CA_EPI_GATE_RESIDUAL || epi == CA_EPI_BIAS)) {
@@ -684,7 +706,8 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
         for (int mq = 0; mq < 4; ++mq) {
           const int mi = mh * 4 + mq;
           const int m = m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
-          const bool first = m < P.gate_rows;
+          const bool first = true;
+          if (gated && straddle) row_gate(m);
           f32x4 *op = (f32x4 *)(outb + ((size_t)m * ldo + nb + col_shift) * 4);
 #pragma unroll
           for (int j = 0; j < NF; ++j) {
@@ -714,7 +737,8 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     for (int mi = 0; mi < 8; ++mi) {
       const int m = m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
       uint2 *op = (uint2 *)(outb + ((size_t)m * ldo + nb + col_shift) * 2);
-      const bool first = m < P.gate_rows;
+      const bool first = true;
+      if (epi == CA_EPI_GATE_RESIDUAL && straddle) row_gate(m);
       uint2 o[NF];
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
@@ -942,6 +966,11 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
         if (!p.resid || !p.gate || (p.ldr % 8 && !p.out_f32) || p.ldc < p.N || ((uintptr_t)p.resid & 15) ||
             ((uintptr_t)p.gate & 15) || ((uintptr_t)p.gate2 & 15) || (p.gate_rows < p.M && !p.gate2)) {
           ca_set_error("%s[%d]: GATE_RESIDUAL needs resid, gate (and gate2 when gate_rows < M), 16-byte aligned", FN, i);
+          return CA_ERR_ARG;
+        }
+        if (p.gate_stride && (p.gate_stride % 4 || p.gate_stride < 0 || (p.gate_rows > 0 && p.gate_item_rows < 1) ||
+                              (p.gate_rows < p.M && p.gate2_item_rows < 1))) {
+          ca_set_error("%s[%d]: per-item gates need gate_stride %% 4 == 0 and gate_item_rows / gate2_item_rows >= 1", FN, i);
           return CA_ERR_ARG;
         }
         break;

@@ -53,6 +53,11 @@ class Gemm:
     q_prerope: Optional[torch.Tensor] = None
     a_scale: Optional[torch.Tensor] = None  # fp8 mode: a, w are uint8 (e4m3 bytes) with fp32 row scales
     w_scale: Optional[torch.Tensor] = None  # ([M] and [N]); the launch then goes to ca_gemm_fp8
+    # batched forward: rows < gate_rows are items of gate_item_rows rows, the others items of gate2_item_rows rows;
+    # item i of a range uses gate (gate2) + i * gate_stride floats.  gate_stride = 0: one vector per range.
+    gate_stride: int = 0
+    gate_item_rows: int = 0
+    gate2_item_rows: int = 0
 
 
 def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
@@ -86,6 +91,7 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
             p.resid, p.ldr = _chk(g.resid, out.dtype, "resid").data_ptr(), g.resid.stride(0)
             p.gate = _chk(g.gate, torch.float32, "gate").data_ptr()
             p.gate2 = _ptr(None if g.gate2 is None else _chk(g.gate2, torch.float32, "gate2"))
+            p.gate_stride, p.gate_item_rows, p.gate2_item_rows = g.gate_stride, g.gate_item_rows, g.gate2_item_rows
         elif g.epilogue == L.EPI_QKV_NORM_ROPE:
             if g.norm_q is None or g.norm_k is None or g.rope is None:
                 raise ValueError(f"gemm[{i}]: QKV_NORM_ROPE needs norm_q, norm_k, rope")
@@ -149,6 +155,8 @@ class Attn:
     k1: Optional[torch.Tensor] = None
     v1: Optional[torch.Tensor] = None
     out_f32: Optional[torch.Tensor] = None  # optional fp32 copy of the output rows
+    q1: Optional[torch.Tensor] = None       # second query-row segment (its rows follow q's) and its output rows
+    out1: Optional[torch.Tensor] = None
 
 
 def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] = None) -> None:
@@ -163,6 +171,13 @@ def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] =
         p.ldq, p.ldo, p.ldkv = a.q.stride(0), a.out.stride(0), a.k0.stride(0)
         if a.v0.stride(0) != p.ldkv or a.v0.shape[0] != p.n0 or a.out.shape[0] != p.nq:
             raise ValueError(f"attention[{i}]: k0/v0/out row mismatch")
+        p.nq0 = p.nq
+        if a.q1 is not None and a.q1.shape[0] > 0:
+            _chk(a.q1, torch.bfloat16, "q1"), _chk(a.out1, torch.bfloat16, "out1")
+            if a.q1.stride(0) != p.ldq or a.out1.stride(0) != p.ldo or a.out1.shape[0] != a.q1.shape[0]:
+                raise ValueError(f"attention[{i}]: both query / output segments must share one row stride")
+            p.q1, p.out1 = a.q1.data_ptr(), a.out1.data_ptr()
+            p.nq = p.nq0 + a.q1.shape[0]
         if a.k1 is not None and a.k1.shape[0] > 0:
             _chk(a.k1, torch.bfloat16, "k1"), _chk(a.v1, torch.bfloat16, "v1")
             if a.k1.stride(0) != p.ldkv or a.v1.stride(0) != p.ldkv or a.v1.shape[0] != a.k1.shape[0]:

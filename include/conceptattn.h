@@ -97,7 +97,10 @@ typedef struct {
   int32_t out_f32;   /* 1: `out` (and `resid`) hold fp32 elements (ldc/ldr still in elements, % 4 == 0); BIAS and
                         GATE_RESIDUAL only.  The fp32 residual stream: img_in / txt_in write it, the attention-
                         and MLP-output projections update it in place; 0: bf16 as above */
-  int32_t _pad;
+  int32_t gate_stride;     /* GATE_RESIDUAL, batched forward: 0 = one gate vector per row range (above); else the */
+  int32_t gate_item_rows;  /* rows < gate_rows are consecutive work items of gate_item_rows rows, the others of     */
+  int32_t gate2_item_rows; /* gate2_item_rows rows, and item i of a range uses its base vector + i * gate_stride   */
+                           /* floats (gate_stride % 4 == 0): every item of a batch has its own adaLN gates         */
 } ca_gemm_problem;
 
 int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile, ca_stream_t stream);
@@ -122,8 +125,13 @@ int ca_gemm_fp8(const ca_gemm_problem *problems, int32_t n_problems, ca_stream_t
  * column h*128 of the pointer given; the output is written head-concatenated ("B H L D -> B L (H D)",
  * modified_double_stream_block.py:170-176).  The key/value set of a problem is the concatenation
  * of two row segments (segment 1 may be empty), e.g. [concept rows ; image rows].
- * Up to 2 problems share one launch (main rows + concept rows).
+ * Up to CA_ATTN_MAX_PROBLEMS problems share one launch (per work item of a batch: its text+image rows, and its
+ * concept rows); their workgroups are laid out in the order given (put the small concept problems first).
+ * The query rows of a problem (and the output rows with them) may themselves come in two row segments: rows
+ * [0, nq0) at q / out, rows [nq0, nq) at q1 / out1 -- in a batched forward an item's text rows and image rows are
+ * not adjacent.  nq0 = 0 or nq0 = nq: one segment (q1 / out1 unused).
  */
+#define CA_ATTN_MAX_PROBLEMS 16
 typedef struct {
   const void *q; /* bf16, row stride ldq */
   void *out;     /* bf16, row stride ldo */
@@ -131,8 +139,12 @@ typedef struct {
   const void *k1, *v1; /* segment 1: n1 rows, row stride ldkv */
   float *out_f32; /* optional fp32 copy of the output rows (row stride ldo32), or NULL: used for the
                      C concept rows so the heat-map products do not see their bf16 rounding */
+  const void *q1; /* second query segment (rows nq0..nq-1), row stride ldq; or NULL */
+  void *out1;     /* its output rows, row stride ldo */
   int32_t nq, n0, n1;
   int32_t ldq, ldo, ldkv, ldo32;
+  int32_t nq0;    /* query rows in the first segment; 0 or nq = all */
+  int32_t _pad[3];
 } ca_attn_problem;
 
 int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
@@ -144,7 +156,7 @@ int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_
  * LastLayer flux/modules/layers.py:250-251.  Row ranges may use different modulation vectors
  * (concept rows / text rows / image rows): segment i covers rows [row_end[i-1], row_end[i]).
  */
-#define CA_MAX_SEGMENTS 4
+#define CA_MAX_SEGMENTS 16
 typedef struct {
   int32_t row_end;
   int32_t _pad;

@@ -34,8 +34,8 @@ def test_version_and_error_string(lib):
 
 def test_struct_layouts_match_header():
     # sizes the C compiler sees (LP64): pointers 8, int32 4, no implicit padding inside
-    assert ctypes.sizeof(L.GemmProblem) == 14 * 8 + 12 * 4
-    assert ctypes.sizeof(L.AttnProblem) == 7 * 8 + 7 * 4 + 4  # trailing pad to 8-byte alignment
+    assert ctypes.sizeof(L.GemmProblem) == 14 * 8 + 16 * 4
+    assert ctypes.sizeof(L.AttnProblem) == 9 * 8 + 8 * 4 + 3 * 4 + 4  # trailing pad to 8-byte alignment
     assert ctypes.sizeof(L.ModSegment) == 24 and ctypes.sizeof(L.NormSegment) == 24
 
 
