@@ -139,8 +139,12 @@ def main():
     ap.add_argument("--concepts", type=int, default=4)
     ap.add_argument("--diffusion-steps", type=int, default=4)
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--streams", type=int, default=2,
-                    help="independent work items kept in flight per GPU on separate HIP streams (throughput mode)")
+    ap.add_argument("--batch", type=int, default=5,
+                    help="work items that share one forward (one launch per kernel for all of them): 5 x 17 row tiles "
+                         "and 5 x 408 attention workgroups fill the 256 CUs to 99.6 %% in the last round of every "
+                         "launch; 1 = one item per forward")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="groups of --batch items kept in flight per GPU on separate HIP streams")
     ap.add_argument("--precision", choices=("bf16", "fp8"), default="bf16",
                     help="fp8: the large projections run on e4m3 operands (reduced-precision mode of "
                          "BASELINE.json configs[4]; NOT the headline metric, which is bf16)")
@@ -195,7 +199,10 @@ def main():
         return {k: inp[k].to(dev) for k in ("latent", "txt", "vec", "concepts")}
 
     timed_items = D.shard_items(n_timed, rank, world)
-    warm_items = [n_timed + rank * args.warmup + i for i in range(args.warmup)]
+    # warm-up: W steps asked; a full group of --batch items is run whenever W > 0, so that the activation set and
+    # every kernel of the batched shape exist before the timed region (more warm-up than asked, never less)
+    n_warm = 0 if args.warmup <= 0 else max(args.warmup, args.batch)
+    warm_items = [n_timed + rank * n_warm + i for i in range(n_warm)]
     inputs = {j: item_inputs(j) for j in timed_items + warm_items}
 
     def run_item(j):
@@ -205,8 +212,10 @@ def main():
                                             guidance=0.0)
         return torch.stack((hm[0], cm[0]))  # [2, C, side, side]
 
-    for j in warm_items:
-        run_item(j)
+    if warm_items:
+        pipe.generate_many_on_device([inputs[j] for j in warm_items], n_streams=args.streams, batch=args.batch,
+                                     layer_indices=layer_indices, num_inference_steps=args.diffusion_steps,
+                                     guidance=0.0)
 
     # ---- per-launch timing of the GEMM kernel with HIP events on the launch stream.  Every event pair
     # costs a ~5 us pipeline drain around the launch (616 GEMM launches per call = 2.3 % of a call), so
@@ -236,18 +245,19 @@ def main():
     D.barrier()
     t0 = time.perf_counter()
     local_maps = []
-    head, last = timed_items[:-1], timed_items[-1]
-    if args.streams > 1 and head:  # throughput mode: `streams` items in flight; the last timed step runs alone
-        res = pipe.generate_many_on_device([inputs[j] for j in head], n_streams=args.streams,
-                                           layer_indices=layer_indices, num_inference_steps=args.diffusion_steps,
-                                           guidance=0.0)
+    # the LAST group of --batch items runs with the per-launch HIP-event timing; the groups before it unperturbed
+    n_last = min(max(1, args.batch), len(timed_items))
+    head, last = timed_items[:-n_last], timed_items[-n_last:]
+    gen_kw = dict(layer_indices=layer_indices, num_inference_steps=args.diffusion_steps, guidance=0.0)
+    if head:
+        res = pipe.generate_many_on_device([inputs[j] for j in head], n_streams=args.streams, batch=args.batch,
+                                           **gen_kw)
         local_maps += [torch.stack((hm[0], cm[0])) for _, hm, cm in res]
-    else:
-        local_maps += [run_item(j) for j in head]
     if not args.no_kernel_timing:
         ops.set_gemm_hook(hook)
         ops.set_attn_hook(attn_hook)
-    local_maps.append(run_item(last))
+    res = pipe.generate_many_on_device([inputs[j] for j in last], n_streams=1, batch=args.batch, **gen_kw)
+    local_maps += [torch.stack((hm[0], cm[0])) for _, hm, cm in res]
     ops.set_gemm_hook(None)
     ops.set_attn_hook(None)
     local_maps = torch.stack(local_maps)
@@ -265,7 +275,8 @@ def main():
     block = None
     if rank == 0:
         m = pipe.model
-        i0 = inputs[timed_items[0]]
+        nb = max(1, min(args.batch, len(timed_items)))   # the forward holds --batch items; times are per item
+        i0 = {k: torch.cat([inputs[j][k] for j in timed_items[:nb]], 0) for k in ("latent", "txt", "vec", "concepts")}
         from conceptattention_amd import sampling as S_
         con, con_ids, con_vec = S_.concept_inputs(i0["concepts"], i0["vec"])
         inp0 = S_.prepare_from_embeddings(i0["latent"].to(dev, torch.bfloat16), i0["txt"], i0["vec"])
@@ -281,17 +292,18 @@ def main():
         m._double_block = timed_block
         try:
             m(img=inp0["img"], img_ids=inp0["img_ids"], txt=inp0["txt"], txt_ids=inp0["txt_ids"], concepts=con,
-              concept_ids=con_ids, concept_vec=con_vec, y=inp0["vec"], timesteps=torch.full((1,), 1.0, device=dev),
-              guidance=torch.zeros(1, device=dev), stop_after_multimodal_attentions=True, return_vectors=False)
+              concept_ids=con_ids, concept_vec=con_vec, y=inp0["vec"], timesteps=torch.full((nb,), 1.0, device=dev),
+              guidance=torch.zeros(nb, device=dev), stop_after_multimodal_attentions=True, return_vectors=False)
         finally:
             m._double_block = orig
         torch.cuda.synchronize()
-        us = sorted(s_.elapsed_time(e_) * 1e3 for s_, e_ in evs)
+        us = sorted(s_.elapsed_time(e_) * 1e3 / nb for s_, e_ in evs)
         med = us[len(us) // 2]
         H_, MLP_, NH_, D_ = p.hidden_size, p.mlp_hidden, p.num_heads, p.head_dim
         dbl_flops = ((2 * H_ * 3 * H_ + 2 * H_ * H_ + 4 * H_ * MLP_) * (Lp + T + C) + 4 * (Lp + T) ** 2 * D_ * NH_
                      + 4 * C * (C + Lp) * D_ * NH_ + 3 * 2 * H_ * 6 * H_)
-        block = {"what": "ModifiedDoubleStreamBlock-equivalent (7 launches), median of 19", "us": med,
+        block = {"what": f"ModifiedDoubleStreamBlock-equivalent (7 launches for {nb} work items), median of 19, "
+                         "per work item", "us": med,
                  "tflop": dbl_flops / 1e12, "achieved_tflops": dbl_flops / med / 1e6,
                  "mfma_frac": dbl_flops / med / 1e6 / MFMA_BF16_PEAK_TFLOPS}
     maps_ok = bool(torch.isfinite(all_maps).all().item()) and abs(all_maps[:, 0].sum(1).mean().item() - 1.0) < 1e-3
@@ -320,8 +332,8 @@ def main():
                 names[5] = "ca_gemm_pp_kernel<2,2,fp8> (256x256x128 ping-pong, e4m3)"
             roof.update(kernel=names.get(tile, str(tile)), launches=n, avg_launch_us=sec / n * 1e6,
                         flops_per_launch=fl / n, achieved=fl / sec / 1e12,
-                        timed_on="last timed step of rank 0",
-                        share_of_that_step=sec / (elapsed / max(len(timed_items), 1)))
+                        timed_on=f"last group of {n_last} work items of rank 0 (one forward per diffusion step)",
+                        share_of_that_group=sec / (elapsed * n_last / max(len(timed_items), 1)))
         else:
             roof.update(kernel="whole path", achieved=path_tflops)
         roof_attn = None
@@ -332,8 +344,8 @@ def main():
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": len(attn_records),
                          "avg_launch_us": sec / len(attn_records) * 1e6, "flops_per_launch": fl / len(attn_records),
                          "achieved": fl / sec / 1e12, "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                         "share_of_that_step": sec / (elapsed / max(len(timed_items), 1)),
-                         "timed_on": "last timed step of rank 0", "traffic": None}
+                         "share_of_that_group": sec / (elapsed * n_last / max(len(timed_items), 1)),
+                         "timed_on": f"last group of {n_last} work items of rank 0", "traffic": None}
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside the process,
         # so this is the rocprofv3 FETCH_SIZE/WRITE_SIZE measurement of this same command, committed
         # under profiles/ (method and the gfx950 x2 FETCH_SIZE correction are recorded in the file)
@@ -372,7 +384,8 @@ def main():
                                    "(generate_image-equivalent call; random-init weights, synthetic latents/embeddings)",
                        "calls_per_step_per_gpu": 1, "heatmap_layers": layer_indices,
                        "tflop_per_call": flops_call / 1e12, "parallelism": f"replica x{world} (work items round-robin)",
-                       "streams_per_gpu": args.streams, "residual_stream": args.residual,
+                       "items_per_forward": args.batch, "streams_per_gpu": args.streams,
+                       "residual_stream": args.residual,
                        **({"fp8_scope": "qkv/proj/mlp/linear1/linear2 of all blocks except double blocks "
                                         f"{layer_indices} (the heat-map layers stay bf16)"} if fp8 else {})},
             "calls_per_s": calls / elapsed,

@@ -664,8 +664,11 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     // fetches the vector per row fragment instead.
     bool straddle = false;
     if (epi == CA_EPI_GATE_RESIDUAL) {
-      const float *g_lo = ca_gate_of(P, m0), *g_hi = ca_gate_of(P, min(m0 + C::BM, M) - 1);
-      straddle = g_lo != g_hi;  // workgroup-uniform
+      // (rows are monotonic in (range, item), so equal end points mean one vector for the whole tile; comparing the
+      // two POINTERS would not do: text rows of other items can lie between two rows that share a vector)
+      const int m_hi = min(m0 + C::BM, M) - 1;
+      const float *g_lo = ca_gate_of(P, m0);
+      straddle = (m0 < P.gate_rows) != (m_hi < P.gate_rows) || g_lo != ca_gate_of(P, m_hi);  // workgroup-uniform
       const float *g1 = g_lo + nb;
 #pragma unroll
       for (int j = 0; j < NF; ++j) {

@@ -122,6 +122,27 @@ class FluxWeights:
 
 
 @dataclass
+class _Geom:
+    """Row geometry of one forward: B work items; rows [0, oT) concept, [oT, oI) text, [oI, n) image."""
+    B: int
+    C: int
+    T: int
+    L: int
+
+    @property
+    def oT(self):
+        return self.B * self.C
+
+    @property
+    def oI(self):
+        return self.B * (self.C + self.T)
+
+    @property
+    def n(self):
+        return self.B * (self.C + self.T + self.L)
+
+
+@dataclass
 class HeatmapRequest:
     """Fused heat-map accumulation (replaces materialising the 478 MB/step dicts that
     compute_heatmaps_from_vectors later slices, concept_attention_pipeline.py:57-82)."""
@@ -203,6 +224,11 @@ class HipFluxDiT:
             self._fp8_weights()
         return self
 
+    @staticmethod
+    def _launch_gemm(problems):
+        """One grouped GEMM launch (image-weight rows + text-weight rows of all work items)."""
+        ops.gemm(problems)
+
     def _gemm(self, fp8, a, a8, a8s, wname, bias, out, *args, **kw):
         """One problem of a grouped launch in the current precision."""
         if fp8:
@@ -227,13 +253,17 @@ class HipFluxDiT:
         return self
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, L_img: int, T: int, C: int):
-        key = (L_img, T, C, self.precision, self.residual_dtype)
+    def _workspace(self, L_img: int, T: int, C: int, B: int = 1):
+        """Activation set for a batch of B work items.  Rows are ordered
+        [concept rows of item 0..B-1 | text rows of item 0..B-1 | image rows of item 0..B-1]: all rows that use
+        the text weights are one contiguous matrix, all image rows another, and the single blocks' [text | image]
+        rows a third (B = 1: the layout of the module docstring)."""
+        key = (L_img, T, C, B, self.precision, self.residual_dtype)
         if self._ws_key == key:
             return
         p, dev = self.params, self.device
         H, MLP = p.hidden_size, p.mlp_hidden
-        n = C + T + L_img
+        n = B * (C + T + L_img)
         bf = dict(device=dev, dtype=torch.bfloat16)
         f32 = dict(device=dev, dtype=torch.float32)
         self.X = torch.zeros(n, H, device=dev, dtype=self.residual_dtype)
@@ -241,25 +271,25 @@ class HipFluxDiT:
         self.QKV = torch.zeros(n, 3 * H, **bf)
         self.ATT = torch.zeros(n, H, **bf)
         self.HID = torch.zeros(n, MLP, **bf)
-        self.CAT = torch.zeros(T + L_img, H + MLP, **bf)
+        self.CAT = torch.zeros(B * (T + L_img), H + MLP, **bf)
         self.QPRE = torch.zeros(n, H, **bf)
-        self.ATT32 = torch.zeros(max(C, 1), H, **f32)  # fp32 copy of the concept attention rows
-        self.TXT_IN = torch.zeros(C + T, p.context_in_dim, **bf)
-        self.PRED = torch.zeros(L_img, p.in_channels, **bf)
+        self.ATT32 = torch.zeros(max(B * C, 1), H, **f32)  # fp32 copy of the concept attention rows
+        self.TXT_IN = torch.zeros(B * (C + T), p.context_in_dim, **bf)
+        self.PRED = torch.zeros(B * L_img, p.in_channels, **bf)
         self.ROPE = torch.zeros(n, 64, 2, **f32)
-        self.TEMB = torch.zeros(2, 256, **f32)
-        self.TVAL = torch.zeros(2, **f32)
-        self.YIN = torch.zeros(2, p.vec_in_dim, **f32)
-        self.HVEC = torch.zeros(2, H, **f32)
-        self.VEC = torch.zeros(2, H, **f32)
-        self.MOD = torch.zeros(2, self.weights.mod_rows, **f32)
+        self.TEMB = torch.zeros(2 * B, 256, **f32)      # rows 2j / 2j+1: item j's vec / concept_vec chain
+        self.TVAL = torch.zeros(2 * B, **f32)
+        self.YIN = torch.zeros(2 * B, p.vec_in_dim, **f32)
+        self.HVEC = torch.zeros(2 * B, H, **f32)
+        self.VEC = torch.zeros(2 * B, H, **f32)
+        self.MOD = torch.zeros(B, 2, self.weights.mod_rows, **f32)
         self.LOGITS = torch.zeros(max(C, 1), L_img, **f32)
         if self.precision == "fp8":   # e4m3 images of the GEMM inputs + one fp32 scale per row
             u8 = dict(device=dev, dtype=torch.uint8)
             self.XM8, self.XMS = torch.zeros(n, H, **u8), torch.zeros(n, **f32)
             self.ATT8, self.ATTS = torch.zeros(n, H, **u8), torch.zeros(n, **f32)
             self.HID8, self.HIDS = torch.zeros(n, MLP, **u8), torch.zeros(n, **f32)
-            self.CAT8, self.CATS = torch.zeros(T + L_img, H + MLP, **u8), torch.zeros(T + L_img, **f32)
+            self.CAT8, self.CATS = torch.zeros(B * (T + L_img), H + MLP, **u8), torch.zeros(B * (T + L_img), **f32)
         self._ws_key = key
         self._rope_key = None
 
@@ -283,7 +313,8 @@ class HipFluxDiT:
             key = None
         if key is not None and self._rope_key == key:
             return
-        ids = torch.cat((concept_ids[0], txt_ids[0], img_ids[0]), 0).to(self.device, torch.float64)
+        ids = torch.cat((concept_ids.reshape(-1, 3), txt_ids.reshape(-1, 3), img_ids.reshape(-1, 3)), 0) \
+            .to(self.device, torch.float64)
         col = 0
         for a, d in enumerate(self.params.axes_dim):
             scale = torch.arange(0, d, 2, dtype=torch.float64, device=self.device) / d
@@ -294,11 +325,13 @@ class HipFluxDiT:
             col += d // 2
         self._rope_key = key
 
-    def _mod(self, name: str, row: int, chunk: int) -> torch.Tensor:
-        """fp32 view of one modulation chunk: name = '<block>.lin' base, row 0 = vec, 1 = concept_vec."""
+    def _mod(self, name: str, row: int, chunk: int, item: int = 0) -> torch.Tensor:
+        """fp32 view of one modulation chunk of work item ``item``: name = '<block>.lin' base, row 0 = vec,
+        1 = concept_vec.  Consecutive items are ``self._mod_cur.stride(0)`` floats apart (the gate_stride of the
+        GEMM epilogue)."""
         H = self.hidden_size
         o = self.weights.mod_offset[name] + chunk * H
-        return self._mod_cur[row, o:o + H]
+        return self._mod_cur[item, row, o:o + H]
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -306,111 +339,83 @@ class HipFluxDiT:
     def __call__(self, img, img_ids, txt, txt_ids, concepts, concept_ids, concept_vec, timesteps, y,
                  guidance=None, stop_after_multimodal_attentions: bool = False, edit_metadata=None,
                  iteration=None, joint_attention_kwargs=None, return_vectors: bool = True,
-                 heatmaps: Optional[HeatmapRequest] = None, cond_slot: Optional[int] = None, **kwargs):
-        """Same keyword contract as ModifiedFluxDiT.forward (modified_flux_dit.py:75-92).
+                 heatmaps=None, cond_slot: Optional[int] = None, **kwargs):
+        """Same keyword contract as ModifiedFluxDiT.forward (modified_flux_dit.py:75-92), for a batch of B
+        independent work items (the reference's callers use B = 1): img (B,L,64), txt (B,T,4096), concepts
+        (B,C,4096), y / concept_vec (B,768), timesteps / guidance (B,), ids (B,n,3).
 
         Extra (HIP-path) keywords: ``return_vectors=False`` skips materialising the four
-        per-layer vector stacks (the dict is then empty); ``heatmaps`` accumulates
-        softmax-over-concepts maps for the requested layers inside the forward; ``cond_slot=i``
+        per-layer vector stacks (the dict is then empty); ``heatmaps`` (one HeatmapRequest, or a list of B)
+        accumulates softmax-over-concepts maps for the requested layers inside the forward; ``cond_slot=i``
         uses step i of a preceding ``precompute_conditioning`` call instead of recomputing the
         conditioning vectors from ``timesteps`` / ``y`` / ``guidance``."""
         assert concept_vec is not None, "Concept vectors must be provided for this implementation."
         if img.ndim != 3 or txt.ndim != 3:
             raise ValueError("Input img and txt tensors must have 3 dimensions.")
-        if img.shape[0] != 1 or txt.shape[0] != 1 or concepts.shape[0] != 1:
-            raise NotImplementedError("HipFluxDiT: batch size 1 only (the reference path is B=1 as well)")
+        B = img.shape[0]
+        if txt.shape[0] != B or concepts.shape[0] != B:
+            raise ValueError("img, txt and concepts must have the same batch size")
+        if 2 * B > L.ATTN_MAX_PROBLEMS:
+            raise NotImplementedError(f"HipFluxDiT: at most {L.ATTN_MAX_PROBLEMS // 2} work items per forward")
         p, W = self.params, self.weights
         if p.guidance_embed and guidance is None:
             raise ValueError("Didn't get guidance strength for guidance distilled model.")
-        H, NH, MLP = p.hidden_size, p.num_heads, p.mlp_hidden
         Li, T, C = img.shape[1], txt.shape[1], concepts.shape[1]
-        self._workspace(Li, T, C)
+        self._workspace(Li, T, C, B)
         self._rope_table(img_ids, txt_ids, concept_ids, C, T)
-        n = C + T + Li
-        CT = C + T
-        X, XM, QKV, ATT, HID, CAT = self.X, self.XM, self.QKV, self.ATT, self.HID, self.CAT
+        g = _Geom(B, C, T, Li)
+        X, XM = self.X, self.XM
         bf = torch.bfloat16
+        if heatmaps is not None and not isinstance(heatmaps, (list, tuple)):
+            heatmaps = [heatmaps]
+        if heatmaps is not None and len(heatmaps) != B:
+            raise ValueError("heatmaps: one HeatmapRequest per work item")
 
         # ---- input embeddings: img_in, txt_in (text and concept tokens share txt_in, :105,120)
-        self.TXT_IN[:C].copy_(concepts[0])
-        self.TXT_IN[C:].copy_(txt[0])
-        img_in = img[0].to(bf).contiguous()
-        ops.gemm([ops.Gemm(img_in, W["img_in.weight"], W["img_in.bias"], X[CT:]),
-                  ops.Gemm(self.TXT_IN, W["txt_in.weight"], W["txt_in.bias"], X[:CT])])
+        self.TXT_IN[:g.oT].copy_(concepts.reshape(B * C, -1))
+        self.TXT_IN[g.oT:].copy_(txt.reshape(B * T, -1))
+        img_in = img.reshape(B * Li, -1).to(bf).contiguous()
+        self._launch_gemm([ops.Gemm(img_in, W["img_in.weight"], W["img_in.bias"], X[g.oI:]),
+                           ops.Gemm(self.TXT_IN, W["txt_in.weight"], W["txt_in.bias"], X[:g.oI])])
 
         # ---- conditioning vectors: row 0 = vec (y), row 1 = concept_vec (modified_flux_dit.py:99-119)
         if cond_slot is not None:
             self._mod_cur = self._mod_steps[cond_slot]
+            if self._mod_cur.shape[0] != B:
+                raise ValueError("precompute_conditioning was run for a different batch size")
         else:
             self._mod_cur = self.MOD
-            self._conditioning(timesteps, y, concept_vec, guidance)
+            self._conditioning(timesteps, y, concept_vec, guidance, B)
 
         out = {k: [] for k in DICT_KEYS} if return_vectors else {}
         for i in range(p.depth):
-            self._double_block(i, C, T, Li, joint_attention_kwargs, out, return_vectors, heatmaps)
+            self._double_block(i, g, joint_attention_kwargs, out, return_vectors, heatmaps)
         if return_vectors:
             out = {k: torch.stack(v, 0) for k, v in out.items()}
         if stop_after_multimodal_attentions:
             return None, out
         for i in range(p.depth_single_blocks):
-            self._single_block(i, C, T, Li)
+            self._single_block(i, g)
 
         # ---- LastLayer on the image rows (flux/modules/layers.py:242-253)
         fm = "final_layer.adaLN_modulation.1"
-        ops.ln_modulate(X[CT:], XM[CT:], [(Li, self._mod(fm, 0, 0), self._mod(fm, 0, 1))])
-        ops.gemm([ops.Gemm(XM[CT:], W["final_layer.linear.weight"], W["final_layer.linear.bias"], self.PRED)])
-        return self.PRED.unsqueeze(0).clone(), out
+        ops.ln_modulate(X[g.oI:], XM[g.oI:], [((j + 1) * Li, self._mod(fm, 0, 0, j), self._mod(fm, 0, 1, j))
+                                              for j in range(B)])
+        self._launch_gemm([ops.Gemm(XM[g.oI:], W["final_layer.linear.weight"], W["final_layer.linear.bias"], self.PRED)])
+        return self.PRED.view(B, Li, -1).clone(), out
 
-    def _conditioning(self, timesteps, y, concept_vec, guidance):
-        """vec / concept_vec and all modulations for ONE step into self.VEC / self.MOD."""
+    def _vec_chain(self, tv, yin, gv, hv, vecs):
+        """vec = time_in(t) (+ guidance_in(g)) + vector_in(y) for every row of tv / yin (MLPEmbedders,
+        modified_flux_dit.py:99-119), at most 4 vectors per weight pass."""
         p, W = self.params, self.weights
-        self.TVAL.copy_(timesteps.reshape(-1)[:1].float().expand(2))
-        ops.timestep_embedding(self.TVAL, self.TEMB)
-        ops.gemv(self.TEMB, W["time_in.in_layer.weight"], W["time_in.in_layer.bias"], self.HVEC)
-        ops.gemv(self.HVEC, W["time_in.out_layer.weight"], W["time_in.out_layer.bias"], self.VEC, silu_input=True)
-        if p.guidance_embed:
-            self.TVAL.copy_(guidance.reshape(-1)[:1].float().expand(2))
-            ops.timestep_embedding(self.TVAL, self.TEMB)
-            ops.gemv(self.TEMB, W["guidance_in.in_layer.weight"], W["guidance_in.in_layer.bias"], self.HVEC)
-            ops.gemv(self.HVEC, W["guidance_in.out_layer.weight"], W["guidance_in.out_layer.bias"], self.VEC,
-                     silu_input=True, accumulate=True)
-        self.YIN[0].copy_(y.reshape(-1))
-        self.YIN[1].copy_(concept_vec.reshape(-1))
-        ops.gemv(self.YIN, W["vector_in.in_layer.weight"], W["vector_in.in_layer.bias"], self.HVEC)
-        ops.gemv(self.HVEC, W["vector_in.out_layer.weight"], W["vector_in.out_layer.bias"], self.VEC,
-                 silu_input=True, accumulate=True)
-        self._modulations()
-
-    @on_own_device
-    def precompute_conditioning(self, timesteps, y, concept_vec, guidance=None):
-        """Conditioning vectors and every block's adaLN modulation for ALL diffusion steps up front
-        (they depend only on (t, guidance, y), never on the activations): the 6.4 GB of modulation
-        weights are streamed once per 2 steps instead of once per step.  Step i is then selected
-        with ``cond_slot=i`` in the model call.  Same arithmetic as the in-call path
-        (modified_flux_dit.py:99-119, flux/modules/layers.py:113-126)."""
-        p, W, dev = self.params, self.weights, self.device
-        if p.guidance_embed and guidance is None:
-            raise ValueError("Didn't get guidance strength for guidance distilled model.")
-        n = len(timesteps)
-        H = p.hidden_size
-        f32 = dict(device=dev, dtype=torch.float32)
-        tv = torch.tensor([float(t) for t in timesteps for _ in range(2)], **f32)
-        temb = torch.empty(2 * n, 256, **f32)
-        hv = torch.empty(2 * n, H, **f32)
-        vecs = torch.empty(2 * n, H, **f32)
-        yin = torch.empty(2 * n, p.vec_in_dim, **f32)
-        yin[0::2] = y.reshape(1, -1).float()
-        yin[1::2] = concept_vec.reshape(1, -1).float()
-        mod = torch.empty(n, 2, W.mod_rows, **f32)
-        mod2 = mod.view(2 * n, W.mod_rows)
+        n = tv.shape[0]
+        temb = torch.empty(n, 256, device=self.device, dtype=torch.float32)
         ops.timestep_embedding(tv, temb)
         if p.guidance_embed:
-            gemb = torch.empty(2 * n, 256, **f32)
-            ops.timestep_embedding(torch.full((2 * n,), float(guidance), **f32), gemb)
-        # 4 vectors (= 2 steps) per pass: 4 x 3072 fp32 inputs leave room for 3 workgroups per CU in LDS;
-        # with 8 the weight stream drops from 5.3 to 2.2 TB/s (measured, tools/gemv_bench.py)
-        for r0 in range(0, 2 * n, 4):
-            r = slice(r0, min(r0 + 4, 2 * n))
+            gemb = torch.empty(n, 256, device=self.device, dtype=torch.float32)
+            ops.timestep_embedding(gv, gemb)
+        for r0 in range(0, n, 4):
+            r = slice(r0, min(r0 + 4, n))
             ops.gemv(temb[r], W["time_in.in_layer.weight"], W["time_in.in_layer.bias"], hv[r])
             ops.gemv(hv[r], W["time_in.out_layer.weight"], W["time_in.out_layer.bias"], vecs[r], silu_input=True)
             if p.guidance_embed:
@@ -420,23 +425,74 @@ class HipFluxDiT:
             ops.gemv(yin[r], W["vector_in.in_layer.weight"], W["vector_in.in_layer.bias"], hv[r])
             ops.gemv(hv[r], W["vector_in.out_layer.weight"], W["vector_in.out_layer.bias"], vecs[r],
                      silu_input=True, accumulate=True)
+
+    def _conditioning(self, timesteps, y, concept_vec, guidance, B=1):
+        """vec / concept_vec of every work item and all modulations for ONE step into self.VEC / self.MOD."""
+        p = self.params
+        t = timesteps.reshape(-1).float()
+        self.TVAL.view(B, 2).copy_((t if t.numel() == B else t[:1].expand(B))[:, None].expand(B, 2))
+        self.YIN.view(B, 2, -1)[:, 0].copy_(y.reshape(B, -1))
+        self.YIN.view(B, 2, -1)[:, 1].copy_(concept_vec.reshape(B, -1))
+        gv = None
+        if p.guidance_embed:
+            gq = guidance.reshape(-1).float()
+            gv = (gq if gq.numel() == B else gq[:1].expand(B))[:, None].expand(B, 2).reshape(-1).contiguous()
+        self._vec_chain(self.TVAL, self.YIN, gv, self.HVEC, self.VEC)
+        self._modulations()
+
+    @on_own_device
+    def precompute_conditioning(self, timesteps, y, concept_vec, guidance=None):
+        """Conditioning vectors and every block's adaLN modulation for ALL diffusion steps (and all work items of
+        a batch: y / concept_vec (B,768)) up front -- they depend only on (t, guidance, y), never on the
+        activations: the 6.4 GB of modulation weights are streamed once per 4 vectors instead of once per step.
+        Step i is then selected with ``cond_slot=i`` in the model call.  Same arithmetic as the in-call path
+        (modified_flux_dit.py:99-119, flux/modules/layers.py:113-126)."""
+        p, W, dev = self.params, self.weights, self.device
+        if p.guidance_embed and guidance is None:
+            raise ValueError("Didn't get guidance strength for guidance distilled model.")
+        n = len(timesteps)
+        y = y.reshape(-1, p.vec_in_dim)
+        B = y.shape[0]
+        H = p.hidden_size
+        f32 = dict(device=dev, dtype=torch.float32)
+        # row order: step, item, (vec | concept_vec)
+        tv = torch.tensor([float(t) for t in timesteps for _ in range(2 * B)], **f32)
+        hv = torch.empty(2 * B * n, H, **f32)
+        vecs = torch.empty(2 * B * n, H, **f32)
+        yin = torch.empty(n, B, 2, p.vec_in_dim, **f32)
+        yin[:, :, 0] = y.float()
+        yin[:, :, 1] = concept_vec.reshape(B, -1).float()
+        yin = yin.view(2 * B * n, -1)
+        gv = None
+        if p.guidance_embed:
+            gq = torch.as_tensor(guidance, **f32).reshape(-1)
+            gv = (gq if gq.numel() == B else gq[:1].expand(B))[None, :, None].expand(n, B, 2).reshape(-1).contiguous()
+        mod = torch.empty(n, B, 2, W.mod_rows, **f32)
+        mod2 = mod.view(2 * B * n, W.mod_rows)
+        self._vec_chain(tv, yin, gv, hv, vecs)
+        # 4 vectors per pass: 4 x 3072 fp32 inputs leave room for 3 workgroups per CU in LDS;
+        # with 8 the weight stream drops from 5.3 to 2.2 TB/s (measured, tools/gemv_bench.py)
+        for r0 in range(0, 2 * B * n, 4):
+            r = slice(r0, min(r0 + 4, 2 * B * n))
             ops.gemv(vecs[r], W.mod_w, W.mod_b, mod2[r], silu_input=True)
         self._mod_steps = mod
         return n
 
     def _modulations(self):
-        """Every block's adaLN shift/scale/gate from VEC (row 0 = vec, row 1 = concept_vec) in one
-        weight-streaming launch (Modulation, flux/modules/layers.py:113-126)."""
-        ops.gemv(self.VEC, self.weights.mod_w, self.weights.mod_b, self.MOD, silu_input=True)
+        """Every block's adaLN shift/scale/gate from VEC (rows 2j / 2j+1 = vec / concept_vec of item j) by
+        weight-streaming launches of at most 4 vectors (Modulation, flux/modules/layers.py:113-126)."""
+        mod2 = self.MOD.view(-1, self.weights.mod_rows)
+        for r0 in range(0, mod2.shape[0], 4):
+            r = slice(r0, min(r0 + 4, mod2.shape[0]))
+            ops.gemv(self.VEC[r], self.weights.mod_w, self.weights.mod_b, mod2[r], silu_input=True)
         self._mod_cur = self.MOD
 
-    def _double_block(self, i, C, T, Li, joint_attention_kwargs=None, out=None, return_vectors=False,
-                      heatmaps=None):
-        """ModifiedDoubleStreamBlock.forward (modified_double_stream_block.py:69-204) on the
-        resident X rows [concepts | text | image]; 7 launches."""
+    def _double_block(self, i, g, joint_attention_kwargs=None, out=None, return_vectors=False, heatmaps=None):
+        """ModifiedDoubleStreamBlock.forward (modified_double_stream_block.py:69-204) on the resident X rows
+        [concepts | text | image] of all work items; 7 launches."""
         p, W = self.params, self.weights
         H, NH = p.hidden_size, p.num_heads
-        CT, n = C + T, C + T + Li
+        B, C, T, Li, oT, oI, n = g.B, g.C, g.T, g.L, g.oT, g.oI, g.n
         X, XM, QKV, ATT, HID = self.X, self.XM, self.QKV, self.ATT, self.HID
         qs, ks, vs = QKV[:, :H], QKV[:, H:2 * H], QKV[:, 2 * H:]
         cross = self_ = True
@@ -445,7 +501,7 @@ class HipFluxDiT:
             self_ = joint_attention_kwargs.get("concept_self_attention", True)
         b = f"double_blocks.{i}."
         im, tm = b + "img_mod.lin", b + "txt_mod.lin"
-        capture = return_vectors or (heatmaps is not None and i in heatmaps.layer_indices)
+        capture = return_vectors or (heatmaps is not None and any(i in h.layer_indices for h in heatmaps))
         fp8 = self.precision == "fp8" and i not in self.keep_bf16_layers
         if fp8:
             XM8, XMS, ATT8, ATTS, HID8, HIDS = self.XM8, self.XMS, self.ATT8, self.ATTS, self.HID8, self.HIDS
@@ -456,120 +512,147 @@ class HipFluxDiT:
 
         def rows(t, lo, hi):
             return None if t is None else t[lo:hi]
+
+        def segs(sh, sc):
+            """LayerNorm-modulate segments in row order: concept rows (concept_vec), text rows, image rows of
+            every item; sh / sc = chunk index of shift / scale in the block's modulation."""
+            return ([((j + 1) * C, self._mod(tm, 1, sh, j), self._mod(tm, 1, sc, j)) for j in range(B)] +
+                    [(oT + (j + 1) * T, self._mod(tm, 0, sh, j), self._mod(tm, 0, sc, j)) for j in range(B)] +
+                    [(oI + (j + 1) * Li, self._mod(im, 0, sh, j), self._mod(im, 0, sc, j)) for j in range(B)])
+
+        gs = 0 if B == 1 else self._mod_cur.stride(0)   # floats between consecutive items' gate vectors
         G = self._gemm
-        # K4: LayerNorm + (1+scale)*x+shift, three row segments (:88-89,94-95,100-101)
-        ops.ln_modulate(X, segments=[(C, self._mod(tm, 1, 0), self._mod(tm, 1, 1)),
-                                     (CT, self._mod(tm, 0, 0), self._mod(tm, 0, 1)),
-                                     (n, self._mod(im, 0, 0), self._mod(im, 0, 1))], **xm_out)
+        # K4: LayerNorm + (1+scale)*x+shift, per row range and item (:88-89,94-95,100-101)
+        ops.ln_modulate(X, segments=[sg for sg in segs(0, 1) if sg[0] > 0], **xm_out)
         # K5+K6+K7: qkv projections (image stream + [concept|text] stream in one grouped launch) with
         # QK-RMSNorm and RoPE fused into the epilogue; pre-RoPE q kept for the cross-attention maps
         qpre = self.QPRE if capture else None
-        ops.gemm([G(fp8, XM[CT:], rows(XM8, CT, n), rows(XMS, CT, n), b + "img_attn.qkv.weight",
-                    W.tensors.get(b + "img_attn.qkv.bias"), QKV[CT:],
-                    L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
-                    norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[CT:],
-                    q_prerope=None if qpre is None else qpre[CT:]),
-                  G(fp8, XM[:CT], rows(XM8, 0, CT), rows(XMS, 0, CT), b + "txt_attn.qkv.weight",
-                    W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:CT],
-                    L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
-                    norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:CT],
-                    q_prerope=None if qpre is None else qpre[:CT])])
-        # K8+K9: joint text+image attention and the concept rows in one launch
-        probs = [ops.Attn(qs[C:], ATT[C:], ks[C:], vs[C:])]
-        if C > 0:
-            if cross and self_:
-                probs.append(ops.Attn(qs[:C], ATT[:C], ks[:C], vs[:C], ks[CT:], vs[CT:], out_f32=self.ATT32[:C]))
-            elif cross:   # :129-138 image keys/values only
-                probs.append(ops.Attn(qs[:C], ATT[:C], ks[CT:], vs[CT:], out_f32=self.ATT32[:C]))
-            elif self_:   # :139-147 concept keys/values only
-                probs.append(ops.Attn(qs[:C], ATT[:C], ks[:C], vs[:C], out_f32=self.ATT32[:C]))
-            else:         # :157-159 concept_attn = concept_v
-                ATT[:C].copy_(vs[:C])
-                self.ATT32[:C].copy_(vs[:C])
+        self._launch_gemm([G(fp8, XM[oI:], rows(XM8, oI, n), rows(XMS, oI, n), b + "img_attn.qkv.weight",
+                             W.tensors.get(b + "img_attn.qkv.bias"), QKV[oI:],
+                             L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
+                             norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[oI:],
+                             q_prerope=None if qpre is None else qpre[oI:]),
+                           G(fp8, XM[:oI], rows(XM8, 0, oI), rows(XMS, 0, oI), b + "txt_attn.qkv.weight",
+                             W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:oI],
+                             L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
+                             norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:oI],
+                             q_prerope=None if qpre is None else qpre[:oI])])
+        # K8+K9: per item, joint text+image attention and the concept rows; one launch (concept problems first)
+        probs = []
+        for j in range(B):
+            cj, tj, ij = slice(j * C, (j + 1) * C), slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)
+            if C > 0:
+                if cross and self_:
+                    probs.append(ops.Attn(qs[cj], ATT[cj], ks[cj], vs[cj], ks[ij], vs[ij], out_f32=self.ATT32[cj]))
+                elif cross:   # :129-138 image keys/values only
+                    probs.append(ops.Attn(qs[cj], ATT[cj], ks[ij], vs[ij], out_f32=self.ATT32[cj]))
+                elif self_:   # :139-147 concept keys/values only
+                    probs.append(ops.Attn(qs[cj], ATT[cj], ks[cj], vs[cj], out_f32=self.ATT32[cj]))
+        if C > 0 and not (cross or self_):   # :157-159 concept_attn = concept_v
+            ATT[:oT].copy_(vs[:oT])
+            self.ATT32[:oT].copy_(vs[:oT])
+        for j in range(B):
+            tj, ij = slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)
+            probs.append(ops.Attn(qs[tj], ATT[tj], ks[tj], vs[tj], ks[ij], vs[ij], q1=qs[ij], out1=ATT[ij]))
         ops.attention(probs, NH)
         if capture:
-            self._capture(out, i, C, CT, n, NH, return_vectors, heatmaps)
+            self._capture(out, i, g, NH, return_vectors, heatmaps)
         if fp8:
             ops.quantize_rows_fp8(ATT, ATT8, ATTS)
         # K12: proj + gated residual (:194,198,201); concept rows use txt weights + concept gate
-        ops.gemm([G(fp8, ATT[CT:], rows(ATT8, CT, n), rows(ATTS, CT, n), b + "img_attn.proj.weight",
-                    W[b + "img_attn.proj.bias"], X[CT:],
-                    L.EPI_GATE_RESIDUAL, resid=X[CT:], gate=self._mod(im, 0, 2)),
-                  G(fp8, ATT[:CT], rows(ATT8, 0, CT), rows(ATTS, 0, CT), b + "txt_attn.proj.weight",
-                    W[b + "txt_attn.proj.bias"], X[:CT],
-                    L.EPI_GATE_RESIDUAL, resid=X[:CT], gate=self._mod(tm, 1, 2), gate2=self._mod(tm, 0, 2),
-                    gate_rows=C)])
+        self._launch_gemm([G(fp8, ATT[oI:], rows(ATT8, oI, n), rows(ATTS, oI, n), b + "img_attn.proj.weight",
+                             W[b + "img_attn.proj.bias"], X[oI:],
+                             L.EPI_GATE_RESIDUAL, resid=X[oI:], gate=self._mod(im, 0, 2), gate_stride=gs,
+                             gate_item_rows=Li),
+                           G(fp8, ATT[:oI], rows(ATT8, 0, oI), rows(ATTS, 0, oI), b + "txt_attn.proj.weight",
+                             W[b + "txt_attn.proj.bias"], X[:oI],
+                             L.EPI_GATE_RESIDUAL, resid=X[:oI], gate=self._mod(tm, 1, 2), gate2=self._mod(tm, 0, 2),
+                             gate_rows=oT, gate_stride=gs, gate_item_rows=max(C, 1), gate2_item_rows=T)])
         # K13: LN + modulate + MLP + gated residual (:196,199,202)
-        ops.ln_modulate(X, segments=[(C, self._mod(tm, 1, 3), self._mod(tm, 1, 4)),
-                                     (CT, self._mod(tm, 0, 3), self._mod(tm, 0, 4)),
-                                     (n, self._mod(im, 0, 3), self._mod(im, 0, 4))], **xm_out)
-        ops.gemm([G(fp8, XM[CT:], rows(XM8, CT, n), rows(XMS, CT, n), b + "img_mlp.0.weight",
-                    W[b + "img_mlp.0.bias"], HID[CT:], L.EPI_GELU_TANH),
-                  G(fp8, XM[:CT], rows(XM8, 0, CT), rows(XMS, 0, CT), b + "txt_mlp.0.weight",
-                    W[b + "txt_mlp.0.bias"], HID[:CT], L.EPI_GELU_TANH)])
+        ops.ln_modulate(X, segments=[sg for sg in segs(3, 4) if sg[0] > 0], **xm_out)
+        self._launch_gemm([G(fp8, XM[oI:], rows(XM8, oI, n), rows(XMS, oI, n), b + "img_mlp.0.weight",
+                             W[b + "img_mlp.0.bias"], HID[oI:], L.EPI_GELU_TANH),
+                           G(fp8, XM[:oI], rows(XM8, 0, oI), rows(XMS, 0, oI), b + "txt_mlp.0.weight",
+                             W[b + "txt_mlp.0.bias"], HID[:oI], L.EPI_GELU_TANH)])
         if fp8:
             ops.quantize_rows_fp8(HID, HID8, HIDS)
-        ops.gemm([G(fp8, HID[CT:], rows(HID8, CT, n), rows(HIDS, CT, n), b + "img_mlp.2.weight",
-                    W[b + "img_mlp.2.bias"], X[CT:],
-                    L.EPI_GATE_RESIDUAL, resid=X[CT:], gate=self._mod(im, 0, 5)),
-                  G(fp8, HID[:CT], rows(HID8, 0, CT), rows(HIDS, 0, CT), b + "txt_mlp.2.weight",
-                    W[b + "txt_mlp.2.bias"], X[:CT],
-                    L.EPI_GATE_RESIDUAL, resid=X[:CT], gate=self._mod(tm, 1, 5), gate2=self._mod(tm, 0, 5),
-                    gate_rows=C)])
+        self._launch_gemm([G(fp8, HID[oI:], rows(HID8, oI, n), rows(HIDS, oI, n), b + "img_mlp.2.weight",
+                             W[b + "img_mlp.2.bias"], X[oI:],
+                             L.EPI_GATE_RESIDUAL, resid=X[oI:], gate=self._mod(im, 0, 5), gate_stride=gs,
+                             gate_item_rows=Li),
+                           G(fp8, HID[:oI], rows(HID8, 0, oI), rows(HIDS, 0, oI), b + "txt_mlp.2.weight",
+                             W[b + "txt_mlp.2.bias"], X[:oI],
+                             L.EPI_GATE_RESIDUAL, resid=X[:oI], gate=self._mod(tm, 1, 5), gate2=self._mod(tm, 0, 5),
+                             gate_rows=oT, gate_stride=gs, gate_item_rows=max(C, 1), gate2_item_rows=T)])
 
-    def _single_block(self, i, C, T, Li):
-        """ModifiedSingleStreamBlock.forward (modified_single_stream_block.py:43-56) on the
-        [text | image] rows; 4 launches."""
+    def _single_block(self, i, g):
+        """ModifiedSingleStreamBlock.forward (modified_single_stream_block.py:43-56) on the [text | image] rows of
+        all work items; 4 launches."""
         p, W = self.params, self.weights
         H, NH = p.hidden_size, p.num_heads
-        xs, xms, qkvs, CAT = self.X[C:], self.XM[C:], self.QKV[C:], self.CAT
+        B, T, Li, oT, oI = g.B, g.T, g.L, g.oT, g.oI
+        xs, xms, qkvs, CAT = self.X[oT:], self.XM[oT:], self.QKV[oT:], self.CAT
+        nT = B * T                       # rows of xs that are text; image rows follow
         b = f"single_blocks.{i}."
         m = b + "modulation.lin"
         fp8 = self.precision == "fp8"
         G = self._gemm
-        segs = [(T + Li, self._mod(m, 0, 0), self._mod(m, 0, 1))]
+        segs = ([((j + 1) * T, self._mod(m, 0, 0, j), self._mod(m, 0, 1, j)) for j in range(B)] +
+                [(nT + (j + 1) * Li, self._mod(m, 0, 0, j), self._mod(m, 0, 1, j)) for j in range(B)])
         if fp8:
-            xm8, xms8 = self.XM8[C:], self.XMS[C:]
+            xm8, xms8 = self.XM8[oT:], self.XMS[oT:]
             ops.ln_modulate(xs, xm8, segs, out_scale=xms8)
         else:
             xm8 = xms8 = None
             ops.ln_modulate(xs, xms, segs)
-        ops.gemm([G(fp8, xms, xm8, xms8, b + "linear1.weight", W[b + "linear1.bias"], qkvs, L.EPI_QKV_NORM_ROPE,
-                    out2=CAT[:, H:], n_split=3 * H, norm_q=W[b + "norm.query_norm.scale"],
-                    norm_k=W[b + "norm.key_norm.scale"], rope=self.ROPE[C:])])
-        ops.attention([ops.Attn(qkvs[:, :H], CAT[:, :H], qkvs[:, H:2 * H], qkvs[:, 2 * H:])], NH)
+        self._launch_gemm([G(fp8, xms, xm8, xms8, b + "linear1.weight", W[b + "linear1.bias"], qkvs,
+                             L.EPI_QKV_NORM_ROPE, out2=CAT[:, H:], n_split=3 * H, norm_q=W[b + "norm.query_norm.scale"],
+                             norm_k=W[b + "norm.key_norm.scale"], rope=self.ROPE[oT:])])
+        qh, kh, vh, oh = qkvs[:, :H], qkvs[:, H:2 * H], qkvs[:, 2 * H:], CAT[:, :H]
+        probs = []
+        for j in range(B):
+            tj, ij = slice(j * T, (j + 1) * T), slice(nT + j * Li, nT + (j + 1) * Li)
+            probs.append(ops.Attn(qh[tj], oh[tj], kh[tj], vh[tj], kh[ij], vh[ij], q1=qh[ij], out1=oh[ij]))
+        ops.attention(probs, NH)
         if fp8:
             ops.quantize_rows_fp8(CAT, self.CAT8, self.CATS)
-        ops.gemm([G(fp8, CAT, self.CAT8 if fp8 else None, self.CATS if fp8 else None, b + "linear2.weight",
-                    W[b + "linear2.bias"], xs, L.EPI_GATE_RESIDUAL, resid=xs, gate=self._mod(m, 0, 2))])
+        gate = self._mod(m, 0, 2)
+        self._launch_gemm([G(fp8, CAT, self.CAT8 if fp8 else None, self.CATS if fp8 else None, b + "linear2.weight",
+                             W[b + "linear2.bias"], xs, L.EPI_GATE_RESIDUAL, resid=xs, gate=gate, gate2=gate,
+                             gate_rows=nT, gate_stride=0 if B == 1 else self._mod_cur.stride(0),
+                             gate_item_rows=T, gate2_item_rows=Li)])
 
     forward = __call__
 
-    def _capture(self, out, layer, C, CT, n, NH, return_vectors, heatmaps):
-        """Dict capture (modified_double_stream_block.py:185-191) and/or fused heat-map update."""
+    def _capture(self, out, layer, g, NH, return_vectors, heatmaps):
+        """Dict capture (modified_double_stream_block.py:185-191) and/or fused heat-map update, per work item."""
         ATT, QPRE = self.ATT, self.QPRE
-        if heatmaps is not None and layer in heatmaps.layer_indices:
+        B, C, Li, oT, oI = g.B, g.C, g.L, g.oT, g.oI
+        for j in range(B if heatmaps is not None else 0):
+            hm = heatmaps[j]
+            if layer not in hm.layer_indices:
+                continue
             # output space: the C concept rows come from the fp32 copy the attention kernel wrote
             # (their bf16 rounding, multiplied by the large component all attention outputs share,
             # is the dominant heat-map error otherwise -- DESIGN.md "tolerance")
-            li = heatmaps.layer_indices.index(layer)
-            for img_vec, con_vec, acc, table in ((ATT[CT:], self.ATT32[:C], heatmaps.out_space, heatmaps.per_layer_out),
-                                                 (QPRE[CT:], QPRE[:C], heatmaps.cross_space, heatmaps.per_layer_cross)):
+            li = hm.layer_indices.index(layer)
+            cj, ij = slice(j * C, (j + 1) * C), slice(oI + j * Li, oI + (j + 1) * Li)
+            for img_vec, con_vec, acc, table in ((ATT[ij], self.ATT32[cj], hm.out_space, hm.per_layer_out),
+                                                 (QPRE[ij], QPRE[cj], hm.cross_space, hm.per_layer_cross)):
                 ops.heatmap_logits(img_vec, con_vec, self.LOGITS[:C])
-                ops.heatmap_softmax_accumulate(self.LOGITS[:C], acc, heatmaps.weight, heatmaps.norm)
+                ops.heatmap_softmax_accumulate(self.LOGITS[:C], acc, hm.weight, hm.norm)
                 if table is not None:
-                    ops.heatmap_softmax_accumulate(self.LOGITS[:C], table[li], heatmaps.per_layer_weight,
-                                                   heatmaps.norm)
+                    ops.heatmap_softmax_accumulate(self.LOGITS[:C], table[li], hm.per_layer_weight, hm.norm)
         if return_vectors:
             H = self.hidden_size
-            out["output_space_concept_vectors"].append(ATT[:C].clone()[None])
-            out["output_space_image_vectors"].append(ATT[CT:].clone()[None])
+            cf = torch.contiguous_format
+            out["output_space_concept_vectors"].append(ATT[:oT].view(B, C, H).clone())
+            out["output_space_image_vectors"].append(ATT[oI:].view(B, Li, H).clone())
             # the reference stores post-QKNorm, pre-RoPE q per head: [B, heads, tokens, 128]; in the
             # self-attention-only ablation it rebinds concept_q to the post-RoPE tensor (:140), which
-            # for the all-zero concept ids is the same values
-            # (clone, not .contiguous(): for C = 1 the permuted view already counts as contiguous and would keep
-            # aliasing QPRE, which the next block overwrites)
-            cq = QPRE[:C].view(C, NH, 128).permute(1, 0, 2).clone(memory_format=torch.contiguous_format)[None]
-            iq = QPRE[CT:].view(n - CT, NH, 128).permute(1, 0, 2).clone(memory_format=torch.contiguous_format)[None]
-            out["cross_attention_concept_vectors"].append(cq)
-            out["cross_attention_image_vectors"].append(iq)
+            # for the all-zero concept ids is the same values.  (clone, not .contiguous(): for C = 1 the permuted
+            # view already counts as contiguous and would keep aliasing QPRE, which the next block overwrites)
+            out["cross_attention_concept_vectors"].append(
+                QPRE[:oT].view(B, C, NH, 128).permute(0, 2, 1, 3).clone(memory_format=cf))
+            out["cross_attention_image_vectors"].append(
+                QPRE[oI:].view(B, Li, NH, 128).permute(0, 2, 1, 3).clone(memory_format=cf))

@@ -139,14 +139,18 @@ class ConceptAttentionFluxPipeline:
 
     @torch.no_grad()
     @on_own_device
-    def generate_many_on_device(self, items, n_streams: int = 2, **kw):
-        """Throughput mode: independent work items (dicts with latent/txt/vec/concepts) are kept
-        ``n_streams`` at a time in flight on separate HIP streams of this GPU, each with its own
-        activation set and the shared weights, launches interleaved per diffusion step.  While one
-        item's kernel runs a partial last wave of workgroups (attention: 408 workgroups on 256 CUs,
-        several GEMMs likewise), the idle CUs take the other item's workgroups.  Results are
-        identical to ``generate_on_device`` item by item.  Returns [(img, heat, cross), ...]."""
-        n_streams = max(1, min(n_streams, len(items)))
+    def generate_many_on_device(self, items, n_streams: int = 1, batch: int = 1, **kw):
+        """Throughput mode for independent work items (dicts with latent/txt/vec/concepts, each with a leading
+        batch dimension of 1 and equal shapes).
+
+        ``batch`` items at a time go through ONE forward (one launch per kernel for all of them): the launches then
+        hold 5 x 17 = 85 row tiles / 5 x 408 attention workgroups, which fill the 256 CUs to 99.6 % in their last
+        round, where a single item leaves 15-20 % of the chip idle in every launch.
+        ``n_streams`` groups are kept in flight on separate HIP streams, each with its own activation set and the
+        shared weights.  Every item's result is bit-identical to ``generate_on_device`` on that item alone.
+        Returns [(img, heat, cross), ...] in item order."""
+        groups = [list(range(g0, min(g0 + max(1, batch), len(items)))) for g0 in range(0, len(items), max(1, batch))]
+        n_streams = max(1, min(n_streams, len(groups)))
         while len(self._replicas) < n_streams:
             self._replicas.append(HipFluxDiT(self.params, self.device, weights=self.model.weights,
                                              precision=self.model.precision,
@@ -157,31 +161,37 @@ class ConceptAttentionFluxPipeline:
         cur = torch.cuda.current_stream(self.device)
         self.model.materialize()  # shared fp8 weight images: built on `cur`, which every side stream waits on
         results = [None] * len(items)
-        for g0 in range(0, len(items), n_streams):
-            group = list(range(g0, min(g0 + n_streams, len(items))))
+
+        def cat(idx, key):
+            return torch.cat([items[i][key] for i in idx], 0) if len(idx) > 1 else items[idx[0]][key]
+        for w0 in range(0, len(groups), n_streams):
+            wave = groups[w0:w0 + n_streams]
             gens = {}
-            for slot, i in enumerate(group):
-                st = self._streams[slot]
-                st.wait_stream(cur)
+            for slot, idx in enumerate(wave):
+                st = self._streams[slot] if n_streams > 1 else cur
+                if n_streams > 1:
+                    st.wait_stream(cur)
                 with torch.cuda.stream(st):
-                    it = items[i]
-                    gens[i] = self._generate_steps(self._replicas[slot], it["latent"], it["txt"], it["vec"],
-                                                   it["concepts"], **kw)
+                    gens[slot] = self._generate_steps(self._replicas[slot], cat(idx, "latent"), cat(idx, "txt"),
+                                                      cat(idx, "vec"), cat(idx, "concepts"), **kw)
             alive = dict(gens)
+            done = {}
             while alive:
-                for slot, i in enumerate(group):
-                    if i not in alive:
-                        continue
-                    with torch.cuda.stream(self._streams[slot]):
+                for slot in list(alive):
+                    with torch.cuda.stream(self._streams[slot] if n_streams > 1 else cur):
                         try:
-                            next(alive[i])
+                            next(alive[slot])
                         except StopIteration as stop:
-                            results[i] = stop.value
-                            del alive[i]
-            for slot, i in enumerate(group):
-                cur.wait_stream(self._streams[slot])
-                for t in results[i]:  # allocated on the side stream, consumed on the caller's stream
-                    t.record_stream(cur)
+                            done[slot] = stop.value
+                            del alive[slot]
+            for slot, idx in enumerate(wave):
+                img, hm, cm = done[slot]
+                if n_streams > 1:
+                    cur.wait_stream(self._streams[slot])
+                    for t in (img, hm, cm):  # allocated on the side stream, consumed on the caller's stream
+                        t.record_stream(cur)
+                for k, i in enumerate(idx):
+                    results[i] = (img[k:k + 1], hm[k:k + 1], cm[k:k + 1])
         return results
 
     @torch.no_grad()
@@ -200,10 +210,10 @@ class ConceptAttentionFluxPipeline:
     def _generate_steps(self, model, latent, txt, vec, concept_embeddings, layer_indices=list(range(15, 19)),
                         num_inference_steps: int = 4, guidance: float = 0.0, timesteps=None, fused: bool = True,
                         norm: int = 0):
-        """The device-resident core of generate_image: latent (1,16,h/8,w/8), txt (1,T,4096),
-        vec (1,768), concept_embeddings (1,C,4096) already in HBM -> (final latent tokens,
-        concept heat maps fp32 [1,C,side,side], cross-attention maps fp32 [1,C,side,side]) on the
-        device, no host synchronisation."""
+        """The device-resident core of generate_image for B work items at once (B = 1 from the public API):
+        latent (B,16,h/8,w/8), txt (B,T,4096), vec (B,768), concept_embeddings (B,C,4096) already in HBM ->
+        (final latent tokens, concept heat maps fp32 [B,C,side,side], cross-attention maps fp32
+        [B,C,side,side]) on the device, no host synchronisation."""
         if timesteps is None:
             timesteps = list(range(num_inference_steps))
         x = latent.to(self.device, torch.bfloat16)
@@ -240,16 +250,20 @@ class ConceptAttentionFluxPipeline:
         # (concept_attention_pipeline.py:76-77); the fused accumulation covers distinct pairs only
         if fused and (len(set(ts)) != len(ts) or len(set(ls)) != len(ls)):
             fused = False
+        B = x.shape[0]
         if fused:
-            req = HeatmapRequest(tuple(ls), 1.0 / (len(ts) * len(ls)),
-                                 torch.zeros(C, n_patches, device=self.device),
-                                 torch.zeros(C, n_patches, device=self.device), norm=norm)
+            acc_o = torch.zeros(B, C, n_patches, device=self.device)
+            acc_c = torch.zeros(B, C, n_patches, device=self.device)
+            reqs = [HeatmapRequest(tuple(ls), 1.0 / (len(ts) * len(ls)), acc_o[j], acc_c[j], norm=norm)
+                    for j in range(B)]
             img, _, _ = yield from sampling.denoise_steps(
                 model, **inp, timesteps=schedule, guidance=guidance, concepts=con, concept_ids=con_ids,
-                concept_vec=con_vec, return_intermediate_images=False, return_vectors=False, heatmaps=req,
+                concept_vec=con_vec, return_intermediate_images=False, return_vectors=False, heatmaps=reqs,
                 heatmap_timesteps=ts)
             side = int(round(n_patches ** 0.5))
-            return img, req.out_space.view(1, C, side, side), req.cross_space.view(1, C, side, side)
+            return img, acc_o.view(B, C, side, side), acc_c.view(B, C, side, side)
+        if B != 1:
+            raise NotImplementedError("the stacked (fused=False) route takes one work item at a time")
         img, _, d = yield from sampling.denoise_steps(
             model, **inp, timesteps=schedule, guidance=guidance, concepts=con, concept_ids=con_ids,
             concept_vec=con_vec, return_intermediate_images=False)

@@ -67,39 +67,39 @@ def _tag_ids(t: torch.Tensor, what: tuple) -> torch.Tensor:
     return t
 
 
-def make_img_ids(h2: int, w2: int, device=None) -> torch.Tensor:
-    """img_ids of prepare() (flux/sampling.py:40-43): [0, row, col] per token."""
+def make_img_ids(h2: int, w2: int, device=None, batch: int = 1) -> torch.Tensor:
+    """img_ids of prepare() (flux/sampling.py:40-43): [0, row, col] per token, repeated over the batch."""
     ids = torch.zeros(h2, w2, 3, device=device)
     ids[..., 1] = torch.arange(h2, device=device)[:, None]
     ids[..., 2] = torch.arange(w2, device=device)[None, :]
-    return _tag_ids(ids.reshape(1, h2 * w2, 3), ("img", h2, w2))
+    return _tag_ids(ids.reshape(1, h2 * w2, 3).repeat(batch, 1, 1), ("img", h2, w2, batch))
 
 
-def zero_ids(n: int, device=None) -> torch.Tensor:
+def zero_ids(n: int, device=None, batch: int = 1) -> torch.Tensor:
     """txt_ids of prepare() (flux/sampling.py:50) and concept_ids of embed_concepts (utils.py:26): all zero."""
-    return _tag_ids(torch.zeros(1, n, 3, device=device), ("zero", n))
+    return _tag_ids(torch.zeros(batch, n, 3, device=device), ("zero", n, batch))
 
 
 def prepare_from_embeddings(img: torch.Tensor, txt: torch.Tensor, vec: torch.Tensor) -> dict:
     """prepare() with the T5/CLIP outputs supplied by the caller (they are out of scope here:
     SURVEY.md §2 row 9).  img: latent (1,16,h,w)."""
     bs, c, h, w = img.shape
-    if bs != 1:
-        raise NotImplementedError("batch size 1 only")
+    if txt.shape[0] != bs or vec.shape[0] != bs:
+        raise ValueError("img, txt and vec must have the same batch size")
     return {
         "img": patchify(img),
-        "img_ids": make_img_ids(h // 2, w // 2, img.device),
+        "img_ids": make_img_ids(h // 2, w // 2, img.device, bs),
         "txt": txt.to(img.device),
-        "txt_ids": zero_ids(txt.shape[1], img.device),
+        "txt_ids": zero_ids(txt.shape[1], img.device, bs),
         "vec": vec.to(img.device),
     }
 
 
 def concept_inputs(concept_embeddings: torch.Tensor, vec_like: torch.Tensor):
     """embed_concepts' output contract (concept_attention/utils.py:6-33): first-token embeddings
-    (1,C,4096), all-zero ids (1,C,3) and an all-ZERO pooled vector."""
-    c = concept_embeddings.shape[1]
-    return (concept_embeddings, zero_ids(c, concept_embeddings.device), torch.zeros_like(vec_like))
+    (B,C,4096), all-zero ids (B,C,3) and an all-ZERO pooled vector."""
+    b, c = concept_embeddings.shape[:2]
+    return (concept_embeddings, zero_ids(c, concept_embeddings.device, b), torch.zeros_like(vec_like))
 
 
 @torch.no_grad()
@@ -109,8 +109,8 @@ def denoise(model, img, img_ids, txt, txt_ids, vec, timesteps: list[float], guid
             heatmaps: Optional[HeatmapRequest] = None, heatmap_timesteps=None):
     """Sequential Euler loop of flux/sampling.py:96-152.  Returns (img, intermediates, dict) with
     each dict entry stacked over time.  HIP-path extras: ``return_vectors=False`` +
-    ``heatmaps``/``heatmap_timesteps`` accumulate the concept maps inside the model call for the
-    selected (step, layer) pairs instead of stacking the vectors."""
+    ``heatmaps`` (one HeatmapRequest per work item of the batch) / ``heatmap_timesteps`` accumulate the concept
+    maps inside the model call for the selected (step, layer) pairs instead of stacking the vectors."""
     gen = denoise_steps(model, img, img_ids, txt, txt_ids, vec, timesteps, guidance, concepts, concept_ids,
                         concept_vec, return_intermediate_images, joint_attention_kwargs, return_vectors, heatmaps,
                         heatmap_timesteps)

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from conceptattention_amd import ops  # noqa: E402
-from conceptattention_amd.flux_dit import DICT_KEYS, HeatmapRequest, HipFluxDiT  # noqa: E402
+from conceptattention_amd.flux_dit import DICT_KEYS, HeatmapRequest, HipFluxDiT, _Geom  # noqa: E402
 from conceptattention_amd.heatmaps import compute_heatmaps_from_vectors  # noqa: E402
 from conceptattention_amd.params import FluxParams, tiny_params  # noqa: E402
 from conceptattention_amd.weights import synthetic_inputs, synthetic_state_dict  # noqa: E402
@@ -176,7 +176,7 @@ def test_full_size_double_block_vs_reference_golden(golden):
     m, case, (L, T, C) = _full_block_model("double")
     out = {k: [] for k in DICT_KEYS}
     req = HeatmapRequest((0,), 1.0, torch.zeros(C, L, device=DEV), torch.zeros(C, L, device=DEV))
-    m._double_block(0, C, T, L, None, out, True, req)
+    m._double_block(0, _Geom(1, C, T, L), None, out, True, [req])
     torch.cuda.synchronize()
     rows = torch.from_numpy(g["sample_rows"]).to(DEV)
     CT = C + T
@@ -218,7 +218,7 @@ def test_full_size_double_block_vs_reference_golden(golden):
 def test_full_size_single_block_vs_reference_golden(golden):
     g = golden("single_full.npz")
     m, case, (L, T, C) = _full_block_model("single")
-    m._single_block(0, C, T, L)
+    m._single_block(0, _Geom(1, C, T, L))
     rows = torch.from_numpy(g["sample_rows"]).to(DEV)
     assert maxabs(m.X[C:][rows], g["out_rows"]) < 6e-2
 
@@ -229,7 +229,7 @@ def test_full_size_double_block_dev_token_counts(golden):
     g = golden("block_full_dev.npz")
     m, case, (L, T, C) = _full_block_model("double", T=512, C=8, seed=8)
     req = HeatmapRequest((0,), 1.0, torch.zeros(C, L, device=DEV), torch.zeros(C, L, device=DEV))
-    m._double_block(0, C, T, L, None, None, False, req)
+    m._double_block(0, _Geom(1, C, T, L), None, None, False, [req])
     rows = torch.from_numpy(g["sample_rows"]).to(DEV)
     CT = C + T
     assert maxabs(m.ATT32[:C], g["concept_attn"][0]) < 1e-3   # fp32 copy: no output rounding
@@ -291,7 +291,7 @@ def test_full_size_block_image_stream_ignores_the_concepts():
         m.VEC[0].copy_(base["vec"][0])
         m.VEC[1].copy_(base["concept_vec"][0])
         m._modulations()
-        m._double_block(0, C, T, L, None, None, False, None)
+        m._double_block(0, _Geom(1, C, T, L), None, None, False, None)
         torch.cuda.synchronize()
         outs[tag] = (m.X[C:C + T].clone(), m.X[C + T:].clone(), m.X[:C].clone(), m.ATT32[:C].clone())
     for tag in ("c4_perm", "c1"):

@@ -356,3 +356,65 @@ def test_fp32_residual_is_closer_to_the_oracle_than_bf16_residual():
         assert m.X.dtype == dt
         errs[dt] = (pred.float().cpu() - pred_o).pow(2).mean().sqrt().item()
     assert errs[torch.float32] <= errs[torch.bfloat16] * 1.05, errs
+
+
+# ------------------------------------------------------------------ batched forward (B work items per launch)
+@pytest.mark.parametrize("guidance_embed", [False, True])
+def test_batched_forward_is_bit_identical_to_one_item_at_a_time(guidance_embed):
+    """B items through one forward (rows [concepts of all | text of all | image of all], per-item adaLN vectors and
+    gates, 2B attention problems per launch) give, per item, the bits of a B = 1 forward: pred, all four vector
+    stacks and the fused maps.  Items differ in every input, including the timestep."""
+    from conceptattention_amd.flux_dit import HeatmapRequest
+    p = tiny_params(guidance_embed=guidance_embed)
+    sd = {k: v.bfloat16().float() for k, v in synthetic_state_dict(p, seed=1).items()}
+    B, T, C = 3, 8, 3
+    inps = [{k: (v.bfloat16() if v.is_floating_point() else v).to(DEV)
+             for k, v in synthetic_inputs(p, 256, 256, n_txt=T, n_concepts=C, seed=20 + j).items()} for j in range(B)]
+    ts = torch.tensor([0.9, 0.5, 0.2], device=DEV)
+    gd = torch.tensor([1.0, 2.5, 4.0], device=DEV)
+    m = HipFluxDiT(p, DEV)
+    m.load_state_dict(sd)
+
+    def call(idx, heat):
+        cat = lambda k: torch.cat([inps[j][k] for j in idx], 0)  # noqa: E731
+        img = torch.cat([O.patchify(inps[j]["latent"].float().cpu()).to(DEV, torch.bfloat16) for j in idx], 0)
+        return m(img=img, img_ids=cat("img_ids"), txt=cat("txt"), txt_ids=cat("txt_ids"), concepts=cat("concepts"),
+                 concept_ids=cat("concept_ids"), concept_vec=cat("concept_vec"), y=cat("vec"), timesteps=ts[idx],
+                 guidance=gd[idx], heatmaps=heat)
+    mk = lambda: HeatmapRequest((0, 1), 0.5, torch.zeros(C, 256, device=DEV), torch.zeros(C, 256, device=DEV))  # noqa: E731
+    one = []
+    for j in range(B):
+        h = mk()
+        pred, d = call([j], [h])
+        one.append((pred.clone(), {k: v.clone() for k, v in d.items()}, h))
+    hs = [mk() for _ in range(B)]
+    pred, d = call(list(range(B)), hs)
+    torch.cuda.synchronize()
+    assert pred.shape == (B, 256, p.in_channels)
+    assert d["output_space_image_vectors"].shape == (p.depth, B, 256, p.hidden_size)
+    assert d["cross_attention_concept_vectors"].shape == (p.depth, B, p.num_heads, C, 128)
+    for j in range(B):
+        assert torch.equal(pred[j], one[j][0][0]), j
+        for k in d:
+            assert torch.equal(d[k][:, j], one[j][1][k][:, 0]), (j, k)
+        assert torch.equal(hs[j].out_space, one[j][2].out_space) and torch.equal(hs[j].cross_space, one[j][2].cross_space)
+
+
+def test_generate_many_batched_equals_one_by_one_including_fp8():
+    p = tiny_params()
+    items = []
+    for j in range(7):
+        inp = synthetic_inputs(p, 256, 256, 8, 3, seed=90 + j, dtype=torch.bfloat16)
+        items.append({k: inp[k].to(DEV) for k in ("latent", "txt", "vec", "concepts")})
+    kw = dict(layer_indices=[0, 1], num_inference_steps=2)
+    for precision in ("bf16", "fp8"):
+        pipe = ConceptAttentionFluxPipeline("flux-schnell", device=DEV, weights="synthetic", params=p, n_text_tokens=8,
+                                            precision=precision)
+        seq = [pipe.generate_on_device(i["latent"], i["txt"], i["vec"], i["concepts"], **kw) for i in items]
+        for batch, streams in ((3, 1), (5, 1), (2, 2)):
+            par = pipe.generate_many_on_device(items, n_streams=streams, batch=batch, **kw)
+            torch.cuda.synchronize()
+            assert len(par) == len(items)
+            for a, b in zip(seq, par):
+                for x, y in zip(a, b):
+                    assert x.shape == y.shape and torch.equal(x, y), (precision, batch, streams)

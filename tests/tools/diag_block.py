@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 import torch.nn.functional as F
 from conceptattention_amd import ops
-from conceptattention_amd.flux_dit import HipFluxDiT, HeatmapRequest, DICT_KEYS
+from conceptattention_amd.flux_dit import HipFluxDiT, HeatmapRequest, DICT_KEYS, _Geom
 from conceptattention_amd.params import FluxParams
 from conceptattention_amd.weights import synthetic_state_dict
 from oracle import flux_oracle as O
@@ -44,7 +44,7 @@ xm_img = (1 + im[1]) * O.layer_norm(case["img"]) + im[0]
 xm_con = (1 + cm[1]) * O.layer_norm(case["concepts"]) + cm[0]
 xm_txt = (1 + tm[1]) * O.layer_norm(case["txt"]) + tm[0]
 
-m._double_block(0, C, T, L, None, out, True, req)
+m._double_block(0, _Geom(1, C, T, L), None, out, True, [req])
 torch.cuda.synchronize()
 st("XM(mod2) n/a", m.XM[:C], m.XM[:C])
 qkv_img = O.linear(sd, pfx + "img_attn.qkv", xm_img)
