@@ -550,6 +550,9 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[mi][nj][r] *= sa[mi] * sw[r];
     }
+    // keep the epilogue's loads (bias, gates, residual rows) below this point: hoisted above the scaling they
+    // overlap its temporaries with all 128 accumulators and spill
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue.  acc[mi][nj][r] = C[m][n]:

@@ -41,13 +41,15 @@ def shard_items(n_items: int, rank: int, world: int) -> list[int]:
     return list(range(rank, n_items, world))
 
 
-def gather_heatmaps(local_maps: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:
+def gather_heatmaps(local_maps: torch.Tensor, n_items: int, rank: int, world: int,
+                    force_collective: bool = False) -> torch.Tensor:
     """local_maps [n_local, ...] for items shard_items(n_items, rank, world) -> [n_items, ...] in item
-    order on every rank.  One all_gather of the padded per-rank block (ranks may own one item fewer)."""
+    order on every rank.  One all_gather of the padded per-rank block (ranks may own one item fewer).
+    ``force_collective``: run the collective even in a one-rank group (exercises the RCCL path on a 1-GPU box)."""
     mine = shard_items(n_items, rank, world)
     if local_maps.shape[0] != len(mine):
         raise ValueError(f"rank {rank} holds {local_maps.shape[0]} maps but owns {len(mine)} items")
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return local_maps
     per = (n_items + world - 1) // world
     # RCCL works on the device tensors directly; gloo (CPU rehearsals) goes through host memory
@@ -63,10 +65,10 @@ def gather_heatmaps(local_maps: torch.Tensor, n_items: int, rank: int, world: in
     return full.to(local_maps.device)
 
 
-def allreduce_sum_(acc: torch.Tensor) -> torch.Tensor:
+def allreduce_sum_(acc: torch.Tensor, force_collective: bool = False) -> torch.Tensor:
     """Partial sums of a sharded noise-level sweep (SURVEY.md §8e partitioning 2): one all_reduce of
     the fp32 (C, patches) accumulator."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force_collective):
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     return acc
 

@@ -163,7 +163,8 @@ class HipFluxDiT:
     """Drop-in for the reference's ``ModifiedFluxDiT`` instance on the hot path (inference only)."""
 
     def __init__(self, params: FluxParams, device="cuda:0", weights: Optional[FluxWeights] = None,
-                 attention_block_class=None, precision: str = "bf16", residual_dtype=torch.float32):
+                 attention_block_class=None, precision: str = "bf16", residual_dtype=torch.float32,
+                 bf16_timesteps: bool = False):
         # attention_block_class is accepted for signature compatibility with
         # ModifiedFluxDiT(params, attention_block_class=...) (modified_flux_dit.py:34); the HIP
         # path has exactly one block implementation.
@@ -190,6 +191,12 @@ class HipFluxDiT:
         if residual_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("residual_dtype must be torch.float32 or torch.bfloat16")
         self.residual_dtype = residual_dtype
+        # The reference's production (bf16) run builds t_vec / guidance_vec in the activations' dtype and forms
+        # time_factor * t in bf16 (flux/sampling.py:122-125, flux/modules/layers.py:37): at t = 0.75 it embeds 752,
+        # and most shifted flux-dev schedule values are rounded twice; the embedding itself is cast to bf16 too.
+        # Default False = the fp32 oracle's behaviour (t and 1000 t exact); True reproduces the reference's bf16
+        # values (pinned by tests/golden/timestep_embedding_bf16.npz).
+        self.bf16_timesteps = bool(bf16_timesteps)
         self.set_precision(precision)
 
     # ---- reduced-precision mode (BASELINE.json configs[4]; no counterpart in the reference)
@@ -355,8 +362,9 @@ class HipFluxDiT:
         B = img.shape[0]
         if txt.shape[0] != B or concepts.shape[0] != B:
             raise ValueError("img, txt and concepts must have the same batch size")
-        if 2 * B > L.ATTN_MAX_PROBLEMS:
-            raise NotImplementedError(f"HipFluxDiT: at most {L.ATTN_MAX_PROBLEMS // 2} work items per forward")
+        if 2 * B > L.ATTN_MAX_PROBLEMS or 3 * B > L.MAX_SEGMENTS:
+            raise NotImplementedError(f"HipFluxDiT: at most {min(L.ATTN_MAX_PROBLEMS // 2, L.MAX_SEGMENTS // 3)} work "
+                                      "items per forward (attention problems / LayerNorm segments per launch)")
         p, W = self.params, self.weights
         if p.guidance_embed and guidance is None:
             raise ValueError("Didn't get guidance strength for guidance distilled model.")
@@ -410,10 +418,16 @@ class HipFluxDiT:
         p, W = self.params, self.weights
         n = tv.shape[0]
         temb = torch.empty(n, 256, device=self.device, dtype=torch.float32)
-        ops.timestep_embedding(tv, temb)
-        if p.guidance_embed:
-            gemb = torch.empty(n, 256, device=self.device, dtype=torch.float32)
-            ops.timestep_embedding(gv, gemb)
+        gemb = torch.empty(n, 256, device=self.device, dtype=torch.float32) if p.guidance_embed else None
+        for val, emb in ((tv, temb), (gv, gemb)):
+            if emb is None:
+                continue
+            if self.bf16_timesteps:   # bf16(1000 * bf16(t)) as the kernel's argument, embedding rounded to bf16
+                arg = (val.to(torch.bfloat16) * 1000.0).float()
+                ops.timestep_embedding(arg, emb, time_factor=1.0)
+                emb.copy_(emb.to(torch.bfloat16))
+            else:
+                ops.timestep_embedding(val, emb)
         for r0 in range(0, n, 4):
             r = slice(r0, min(r0 + 4, n))
             ops.gemv(temb[r], W["time_in.in_layer.weight"], W["time_in.in_layer.bias"], hv[r])

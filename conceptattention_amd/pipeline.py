@@ -149,7 +149,8 @@ class ConceptAttentionFluxPipeline:
         ``n_streams`` groups are kept in flight on separate HIP streams, each with its own activation set and the
         shared weights.  Every item's result is bit-identical to ``generate_on_device`` on that item alone.
         Returns [(img, heat, cross), ...] in item order."""
-        groups = [list(range(g0, min(g0 + max(1, batch), len(items)))) for g0 in range(0, len(items), max(1, batch))]
+        batch = max(1, min(batch, _lib.ATTN_MAX_PROBLEMS // 2, _lib.MAX_SEGMENTS // 3))  # launch limits: 5 items
+        groups = [list(range(g0, min(g0 + batch, len(items)))) for g0 in range(0, len(items), batch)]
         n_streams = max(1, min(n_streams, len(groups)))
         while len(self._replicas) < n_streams:
             self._replicas.append(HipFluxDiT(self.params, self.device, weights=self.model.weights,

@@ -18,6 +18,7 @@ Fixtures
   heatmap_kat.npz                   compute_heatmaps_from_vectors known answers (softmax branch)
   sampler.npz                       get_schedule / prepare-patchify / unpack / denoise (tiny, 2 steps)
   metrics.npz                       segmentation scores of concept_attention/utils.py on seeded masks / maps
+  timestep_embedding_bf16.npz       the reference's timestep_embedding on bf16 timesteps (its production dtype)
 """
 from __future__ import annotations
 
@@ -303,6 +304,21 @@ def sampler(ref, out_dir):
     print("sampler done", arrays["schedule_schnell_4"])
 
 
+def timestep_embedding_bf16(ref, out_dir):
+    """The reference's production run keeps the timestep in the activations' bf16 (t_vec / guidance_vec are built
+    in img.dtype, flux/sampling.py:122-125) and `time_factor * t` is then a bf16 product (layers.py:37): at
+    t = 0.75 it embeds 752, not 750.  Golden for HipFluxDiT(bf16_timesteps=True): the reference's own
+    timestep_embedding on bf16 timesteps (both schedules + a guidance value)."""
+    from concept_attention.flux.src.flux.modules.layers import timestep_embedding
+    s = ref["sampling"]
+    ts = s.get_schedule(4, 4096, shift=False)[:-1] + s.get_schedule(50, 4096, shift=True)[:-1] + [3.5, 0.0]
+    t_bf = torch.tensor(ts, dtype=torch.bfloat16)
+    emb = timestep_embedding(t_bf, 256)
+    np.savez_compressed(os.path.join(out_dir, "timestep_embedding_bf16.npz"), t=np.array(ts, np.float64),
+                        emb=emb.float().numpy(), t_bf16=t_bf.float().numpy(), arg_bf16=(1000.0 * t_bf).float().numpy())
+    print("timestep_embedding_bf16", emb.shape)
+
+
 def metrics(ref, out_dir):
     """pixel accuracy / IoU areas / AP of the reference's utils on seeded 2-class cases, driven the way
     experiments/imagenet_segmentation/run_experiment.py:205-219 drives them."""
@@ -339,7 +355,7 @@ def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     ref = _import_reference()
-    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "metrics", "full", "fulldev"]
+    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "metrics", "full", "fulldev", "temb"]
     if "tiny" in which:
         tiny_model(ref, out_dir, False, "tiny_schnell.npz")
         tiny_model(ref, out_dir, True, "tiny_dev.npz")
@@ -351,6 +367,8 @@ def main():
         sampler(ref, out_dir)
     if "metrics" in which:
         metrics(ref, out_dir)
+    if "temb" in which:
+        timestep_embedding_bf16(ref, out_dir)
     if "full" in which:
         full_blocks(ref, out_dir)
     if "fulldev" in which:

@@ -418,3 +418,67 @@ def test_generate_many_batched_equals_one_by_one_including_fp8():
             for a, b in zip(seq, par):
                 for x, y in zip(a, b):
                     assert x.shape == y.shape and torch.equal(x, y), (precision, batch, streams)
+
+
+# ------------------------------------------------------------------ RCCL (one rank: all a 1-GPU box allows)
+def test_rccl_one_rank_group_runs_the_device_collectives():
+    """backend "nccl" IS RCCL on ROCm.  A one-GPU box cannot host two RCCL ranks, but a one-rank group still goes
+    through RCCL's communicator setup and its all_gather / all_reduce kernels on device tensors: the branch of
+    gather_heatmaps / allreduce_sum_ / max_over_ranks that the multi-GPU bench takes."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CA_ROOT"])
+from conceptattention_amd import distributed as D
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+x = torch.arange(3 * 2 * 4 * 8 * 8, dtype=torch.float32, device="cuda:0").view(3, 2, 4, 8, 8)
+full = D.gather_heatmaps(x, 3, 0, 1, force_collective=True)
+assert full.is_cuda and torch.equal(full, x)
+acc = torch.full((4, 64), 2.5, device="cuda:0")
+assert torch.equal(D.allreduce_sum_(acc.clone(), force_collective=True), acc)
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda:0")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+    env = dict(os.environ, CA_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_bf16_timesteps_switch_reproduces_the_reference_embedding(golden):
+    """HipFluxDiT(bf16_timesteps=True) embeds what the reference's bf16 run embeds (752 for t = 0.75): checked on the
+    reference's own timestep_embedding output for both schedules; the default keeps t exact (fp32 oracle)."""
+    g = golden("timestep_embedding_bf16.npz")
+    t = torch.from_numpy(g["t"]).float().to(DEV)
+    arg = (t.to(torch.bfloat16) * 1000.0).float()
+    assert np.array_equal(arg.cpu().numpy(), g["arg_bf16"])          # the argument the reference forms
+    assert float(g["arg_bf16"][1]) == 752.0                           # t = 0.75
+    emb = torch.empty(t.numel(), 256, device=DEV)
+    ops.timestep_embedding(arg, emb, time_factor=1.0)
+    got = emb.to(torch.bfloat16).float().cpu().numpy()
+    # cos / sin of arguments up to 3500 rad in fp32: the device and host libm agree to ~1e-4 before the bf16 cast,
+    # so all but a handful of values land on the same bf16 and none is more than one bf16 step of 1.0 away
+    d = np.abs(got - g["emb"])
+    assert d.max() <= 2 ** -7 and (d > 0).mean() < 0.02
+    # through the model: the switch changes the conditioning at t = 0.75 (750 vs 752), not at t = 0.5 (exact)
+    p = tiny_params(depth=1, depth_single_blocks=0)
+    sd = {k: v.bfloat16().float() for k, v in synthetic_state_dict(p, seed=1).items()}
+    vec = torch.randn(1, p.vec_in_dim, device=DEV)
+    mods = {}
+    for sw in (False, True):
+        m = HipFluxDiT(p, DEV, bf16_timesteps=sw)
+        m.load_state_dict(sd)
+        m.precompute_conditioning([0.75, 0.5], vec, torch.zeros_like(vec))
+        mods[sw] = m._mod_steps.clone()
+    assert not torch.equal(mods[False][0], mods[True][0])
+    assert (mods[False][1] - mods[True][1]).abs().max() < 2e-2 * mods[False][1].abs().max()  # only the bf16 cast of the embedding
