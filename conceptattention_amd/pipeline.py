@@ -351,17 +351,18 @@ class ConceptAttentionFluxPipeline:
     def _encode_maps(self, model, latent, txt, vec, con, con_ids, con_vec, layer_indices, num_samples, num_steps,
                      noise_timestep, seed, stop_after_multi_modal_attentions=True, joint_attention_kwargs=None,
                      norm: int = 0):
-        """Device core of encode_image: one forward per noise sample on ``model``; returns the two fp32 maps
-        [1, C, side, side]."""
-        C = con.shape[1]
+        """Device core of encode_image for B images at once (latent (B,16,h,w), txt (B,T,4096), ...): one forward
+        per noise sample on ``model``; returns the two fp32 maps [B, C, side, side]."""
+        B, C = con.shape[0], con.shape[1]
         n_patches = (latent.shape[-1] // 2) * (latent.shape[-2] // 2)
         height, width = latent.shape[-2] * 8, latent.shape[-1] * 8
         # the reference indexes the stacked samples with the float schedule values
         # (concept_attention_pipeline.py:311, SURVEY.md §3.4), which selects sample 0 only unless
         # a value >= 1; here every sample contributes equally (identical at num_samples=1).
-        req = HeatmapRequest(tuple(int(l) for l in layer_indices), 1.0 / (num_samples * len(layer_indices)),
-                             torch.zeros(C, n_patches, device=self.device),
-                             torch.zeros(C, n_patches, device=self.device), norm=norm)
+        acc_o = torch.zeros(B, C, n_patches, device=self.device)
+        acc_c = torch.zeros(B, C, n_patches, device=self.device)
+        req = [HeatmapRequest(tuple(int(l) for l in layer_indices), 1.0 / (num_samples * len(layer_indices)),
+                              acc_o[j], acc_c[j], norm=norm) for j in range(B)]
         schedule = sampling.get_schedule(num_steps, n_patches, shift=(not self.is_schnell))
         for i in range(num_samples):
             # add_noise_to_image (concept_attention/segmentation.py:85-113)
@@ -369,18 +370,18 @@ class ConceptAttentionFluxPipeline:
             t = schedule[noise_timestep]
             x = (t * noise.float() + (1.0 - t) * latent.float()).to(torch.bfloat16)
             inp = sampling.prepare_from_embeddings(x, txt, vec)
-            t_vec = torch.full((1,), schedule[noise_timestep], device=self.device)
+            t_vec = torch.full((B,), schedule[noise_timestep], device=self.device)
             model(img=inp["img"], img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
                   concepts=con, concept_ids=con_ids, concept_vec=con_vec, y=con_vec, timesteps=t_vec,
-                  guidance=torch.zeros(1, device=self.device),
+                  guidance=torch.zeros(B, device=self.device),
                   stop_after_multimodal_attentions=stop_after_multi_modal_attentions,
                   joint_attention_kwargs=joint_attention_kwargs, return_vectors=False, heatmaps=req)
         side = int(round(n_patches ** 0.5))
-        return req.out_space.view(1, C, side, side), req.cross_space.view(1, C, side, side)
+        return acc_o.view(B, C, side, side), acc_c.view(B, C, side, side)
 
     @torch.no_grad()
     @on_own_device
-    def encode_many_on_device(self, items, n_streams: int = 2, layer_indices=list(range(15, 19)),
+    def encode_many_on_device(self, items, n_streams: int = 1, batch: int = 1, layer_indices=list(range(15, 19)),
                               num_samples: int = 1, num_steps: int = 4, noise_timestep: int = 2, seed: int = 0):
         """Batch form of encode_image for independent images (the loop of
         experiments/imagenet_segmentation/run_experiment.py:137; BASELINE.json configs[3]): ``items`` are dicts with
@@ -388,7 +389,9 @@ class ConceptAttentionFluxPipeline:
         dealt round-robin to ``n_streams`` HIP streams, each with its own activation set (the same throughput
         mode as generate_many_on_device).  Returns [(heat [1,C,s,s], cross [1,C,s,s]), ...], identical to
         encoding the items one by one."""
-        n_streams = max(1, min(n_streams, len(items)))
+        batch = max(1, min(batch, _lib.ATTN_MAX_PROBLEMS // 2, _lib.MAX_SEGMENTS // 3))
+        groups = [list(range(g0, min(g0 + batch, len(items)))) for g0 in range(0, len(items), batch)]
+        n_streams = max(1, min(n_streams, len(groups)))
         while len(self._replicas) < n_streams:
             self._replicas.append(HipFluxDiT(self.params, self.device, weights=self.model.weights,
                                              precision=self.model.precision,
@@ -400,14 +403,18 @@ class ConceptAttentionFluxPipeline:
         self.model.materialize()  # shared fp8 weight images: built on `cur`, which every side stream waits on
         for st in self._streams[:n_streams]:
             st.wait_stream(cur)
-        results = []
-        for i, it in enumerate(items):
-            slot = i % n_streams
+        results = [None] * len(items)
+        for gi, idx in enumerate(groups):   # ``batch`` images share every launch of a forward (see generate_many)
+            slot = gi % n_streams
             with torch.cuda.stream(self._streams[slot]):
-                latent = it["latent"].to(self.device, torch.bfloat16)
-                con, con_ids, con_vec = sampling.concept_inputs(it["concepts"], it["vec"])
-                results.append(self._encode_maps(self._replicas[slot], latent, it["txt"], it["vec"], con, con_ids,
-                                                 con_vec, layer_indices, num_samples, num_steps, noise_timestep, seed))
+                def cat(key):
+                    return torch.cat([items[i][key] for i in idx], 0) if len(idx) > 1 else items[idx[0]][key]
+                latent = cat("latent").to(self.device, torch.bfloat16)
+                con, con_ids, con_vec = sampling.concept_inputs(cat("concepts"), cat("vec"))
+                ho, hc = self._encode_maps(self._replicas[slot], latent, cat("txt"), cat("vec"), con, con_ids, con_vec,
+                                           layer_indices, num_samples, num_steps, noise_timestep, seed)
+                for k, i in enumerate(idx):
+                    results[i] = (ho[k:k + 1], hc[k:k + 1])
         for st in self._streams[:n_streams]:
             cur.wait_stream(st)
         for pair in results:

@@ -219,8 +219,10 @@ def test_encode_many_equals_one_by_one(pipe):
         items.append({k: inp[k].to(DEV) for k in ("latent", "txt", "vec", "concepts")})
     kw = dict(layer_indices=[0, 1], num_samples=2, num_steps=4, noise_timestep=2, seed=5)
     many = pipe.encode_many_on_device(items, n_streams=2, **kw)
+    batched = pipe.encode_many_on_device(items, n_streams=1, batch=3, **kw)   # three images through every launch
     assert len(many) == 3 and many[0][0].shape == (1, 2, 16, 16)
-    for it, (hm, cm) in zip(items, many):
+    for it, (hm, cm), (hb, cb) in zip(items, many, batched):
         one = pipe.encode_many_on_device([it], n_streams=1, **kw)[0]
         assert torch.equal(hm, one[0]) and torch.equal(cm, one[1])
+        assert torch.equal(hb, one[0]) and torch.equal(cb, one[1])
         assert (hm.sum(1) - 1).abs().max() < 1e-5

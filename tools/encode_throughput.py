@@ -11,14 +11,15 @@ dev = "cuda:0"
 p = configs["flux-schnell"]
 pipe = ConceptAttentionFluxPipeline("flux-schnell", device=dev)
 items = []
-for j in range(16):
+for j in range(20):
     inp = synthetic_inputs(p, 1024, 1024, 256, 2, seed=50 + j, device="cpu", dtype=torch.bfloat16)
     items.append({k: inp[k].to(dev) for k in ("latent", "txt", "vec", "concepts")})
-for ns in (1, 2, 1, 2):
-    pipe.encode_many_on_device(items[:2], n_streams=ns, layer_indices=list(range(19)))
+for ns, nb in ((1, 1), (2, 1), (1, 5), (1, 1), (2, 1), (1, 5)):
+    pipe.encode_many_on_device(items[:max(2, nb)], n_streams=ns, batch=nb, layer_indices=list(range(19)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipe.encode_many_on_device(items, n_streams=ns, layer_indices=list(range(19)))
+    pipe.encode_many_on_device(items, n_streams=ns, batch=nb, layer_indices=list(range(19)))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"streams {ns}: {len(items)/dt:.1f} images/s ({dt/len(items)*1e3:.1f} ms per image, 19 layers x 2 spaces of maps)", flush=True)
+    print(f"streams {ns} images per forward {nb}: {len(items)/dt:.1f} images/s ({dt/len(items)*1e3:.1f} ms per image, "
+          "19 layers x 2 spaces of maps)", flush=True)
