@@ -4,8 +4,8 @@
     python tools/profile_round.py --round 2            # in the build container: drives ONE gpurun call
     python tools/profile_round.py --on-box --round 2   # what that call executes on the GPU box
 
-On the box, for the exact bench command (`python3 bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline
---no-kernel-timing`; one stream so that per-kernel durations are exclusive):
+On the box, for the exact bench command (`python3 bench.py --steps 5 --warmup 1 --streams 1 --no-cpu-baseline
+--no-kernel-timing`: one warm-up group and one timed group of 5 work items, one stream, so every launch has the batched shape and per-kernel durations are exclusive):
   1. rocprofv3 --kernel-trace --stats                       -> profiles/rNN_rocprofv3_kernel_stats.csv
   2. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace
                                                             -> profiles/rNN_pmc_mfma_busy.json
@@ -24,7 +24,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = ["python3", "bench.py", "--steps", "2", "--warmup", "1", "--streams", "1", "--no-cpu-baseline",
+BENCH = ["python3", "bench.py", "--steps", "5", "--warmup", "1", "--streams", "1", "--no-cpu-baseline",
          "--no-kernel-timing"]
 
 
