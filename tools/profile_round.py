@@ -70,8 +70,9 @@ def on_box(rnd: int, head: str):
     doc = json.load(open(j))
     doc["git_head"] = head
     json.dump(doc, open(j, "w"), indent=1)
-    # 4. the default, un-profiled bench line (two streams, per-launch HIP-event timing on the last step)
-    r = sh(["python3", "bench.py", "--steps", "8", "--warmup", "1"], env=env, capture_output=True, text=True, check=True)
+    shutil.copy(j, os.path.join(ROOT, "profiles", os.path.basename(j)))  # step 4 reads roofline.traffic from it
+    # 4. the default, un-profiled bench line (groups of 5 work items, per-launch HIP-event timing on the last group)
+    r = sh(["python3", "bench.py", "--steps", "10", "--warmup", "1"], env=env, capture_output=True, text=True, check=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     doc = json.loads(line)
     doc["git_head"] = head
