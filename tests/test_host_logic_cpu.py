@@ -89,3 +89,33 @@ def test_colorize_uses_global_minmax():
     hi = (np.array(plt.get_cmap("plasma")(1.0)[:3]) * 255).astype(np.uint8)
     assert tuple(np.asarray(imgs[0])[1, 1]) == tuple(lo)      # 0.2 is the global minimum
     assert tuple(np.asarray(imgs[1])[0, 0]) == tuple(hi)      # 0.6 is the global maximum
+
+
+def test_batched_prepare_and_id_tags():
+    """prepare / embed_concepts contracts for a batch of work items (flux/sampling.py:31-65, utils.py:6-33 per item)
+    and the content tags HipFluxDiT keys its RoPE-table cache on."""
+    lat = torch.arange(2 * 16 * 4 * 6, dtype=torch.float32).reshape(2, 16, 4, 6)
+    txt, vec = torch.zeros(2, 5, 32), torch.zeros(2, 8)
+    inp = sampling.prepare_from_embeddings(lat, txt, vec)
+    assert inp["img"].shape == (2, 6, 64) and inp["img_ids"].shape == (2, 6, 3) and inp["txt_ids"].shape == (2, 5, 3)
+    for b in range(2):   # every item is patchified and indexed like a batch of one
+        one = sampling.prepare_from_embeddings(lat[b:b + 1], txt[b:b + 1], vec[b:b + 1])
+        assert torch.equal(inp["img"][b], one["img"][0]) and torch.equal(inp["img_ids"][b], one["img_ids"][0])
+    with pytest.raises(ValueError):
+        sampling.prepare_from_embeddings(lat, txt[:1], vec)
+    con, con_ids, con_vec = sampling.concept_inputs(torch.ones(2, 3, 32), vec)
+    assert con_ids.shape == (2, 3, 3) and con_ids.abs().max() == 0 and con_vec.abs().max() == 0
+    a, b = sampling.make_img_ids(4, 2), sampling.make_img_ids(2, 4)
+    assert a._ca_ids_tag[0] == ("img", 4, 2, 1) and b._ca_ids_tag[0] == ("img", 2, 4, 1)   # same shape, different content
+    assert sampling.zero_ids(3, batch=2)._ca_ids_tag[0] == ("zero", 3, 2)
+    v = a._version
+    a[0, 0, 1] = 7.0                                      # an in-place write moves the version: the tag is void
+    assert a._version != v and a._ca_ids_tag[1] == v
+
+
+def test_row_geometry_of_a_batched_forward():
+    from conceptattention_amd.flux_dit import _Geom
+    g = _Geom(B=5, C=4, T=256, L=4096)
+    assert (g.oT, g.oI, g.n) == (20, 1300, 21780)
+    # the single blocks' [text | image] rows of five items are exactly 85 row tiles of 256 (1020 tiles at N = 3072)
+    assert (g.n - g.oT) % 256 == 0 and (g.n - g.oT) // 256 == 85
