@@ -47,6 +47,10 @@ struct Cfg {
   static_assert(BM % 64 == 0, "A/W boundary must be wave-instruction aligned");
 };
 
+#ifndef CA_GEMM_TWO_PHASE
+#define CA_GEMM_TWO_PHASE 1
+#endif
+
 constexpr int GROUP_M = 8;
 
 // Gate vector of output row m (GATE_RESIDUAL).  Rows < gate_rows use `gate`, the others `gate2` (or `gate` when
@@ -483,6 +487,56 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
   __builtin_amdgcn_sched_barrier(0)
 
+#if CA_GEMM_TWO_PHASE
+  // ---- TWO phases per K tile: (A-lo x W-lo, W-hi) then (A-hi x W-lo, W-hi), 32 MFMAs per wave and phase, so the
+  // loop passes 4 barriers per K tile instead of 8 (the barrier hand-off between the two wave groups, not LDS
+  // or MFMA issue, is what the 4-phase loop loses: 2458 vs 2048 cycles per K tile).  Staging and hand-off:
+  //   read segment of phase 1 (tile t): issue W-hi(t+1), A-hi(t+1) into the other buffer -- their tile t-1
+  //     versions were last read by the other group one interval ago, behind a barrier;
+  //   read segment of phase 2: issue A-lo(t+2), W-lo(t+2) into THIS buffer -- both groups read their tile t
+  //     versions in phase 1;
+  //   every read segment ends with vmcnt(what it just issued): everything a wave issued in its PREVIOUS read
+  //     segment (two intervals = ~1000 cycles earlier) has then landed, and the barrier that follows publishes
+  //     it.  First reader of a half tile: W-hi / A-hi(t+1) in phase 1 / 2 of tile t+1, i.e. 4 / 6 intervals after
+  //     the early group issued and 3 / 5 after the late group did, whose retiring read segment is interval 3 / 3:
+  //     one barrier before the read at the closest.  A-lo / W-lo(t+2): 6 intervals.
+  // Prologue: tile 0 complete, A-lo(1), W-lo(1) in flight (retired by phase 1 of tile 0).
+  stageA(0, 0, 0);
+  stageWL(0, 0);
+  stageWH(0, 0);
+  stageA(0, 1, 0);
+  stageA(1, 0, 1);
+  stageWL(1, 1);
+  ca_wait_vmcnt<C::CNT_A + NL>();
+  CA_PP_SYNC();
+  CA_GSTAMP(1);
+  if (wm == 1) { CA_PP_SYNC(); }  // stagger: group 1 runs one barrier behind group 0
+  for (int t = 0; t < nk; ++t) {
+    const int b = t & 1;
+    // phase 1
+    readA(b, 0);
+    readWL(b);
+    readWH(b);
+    stageWH(b ^ 1, t + 1);
+    stageA(b ^ 1, 1, t + 1);
+    CA_PP_WAIT_READS();
+    ca_wait_vmcnt<NHI + C::CNT_A>();
+    CA_PP_SYNC();
+    CA_PP_MMA(0, 0, wl, NL);
+    CA_PP_MMA(0, NL, wh, NHI);
+    CA_PP_SYNC();
+    // phase 2
+    readA(b, 1);
+    stageA(b, 0, t + 2);
+    stageWL(b, t + 2);
+    CA_PP_WAIT_READS();
+    ca_wait_vmcnt<C::CNT_A + NL>();
+    CA_PP_SYNC();
+    CA_PP_MMA(4, 0, wl, NL);
+    CA_PP_MMA(4, NL, wh, NHI);
+    CA_PP_SYNC();
+  }
+#else
   // ---- prologue: AL(0) WL(0) WH(0) AH(0) WL(1).  Group 1 executes no retire-wait between this
   // barrier and group 0's first read of W-hi(0), so everything but AH(0), WL(1) must have landed.
   stageA(0, 0, 0);
@@ -531,6 +585,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     ca_wait_vmcnt<C::CNT_A + NL>();
     CA_PP_SYNC();
   }
+#endif
   if (wm == 0) { CA_PP_SYNC(); }
   ca_wait_vmcnt<0>();  // no LDS-DMA may be outstanding when the workgroup retires
   CA_GSTAMP(2);
