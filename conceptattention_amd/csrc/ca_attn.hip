@@ -24,6 +24,9 @@
 #include <atomic>
 
 #include "ca_common.h"
+#ifndef CA_ATTN_KPF
+#define CA_ATTN_KPF 4
+#endif
 
 namespace {
 
@@ -188,14 +191,25 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 #pragma nounroll
     for (;;) {
       asm volatile("" ::: "memory");  // the K fragments are re-read per pass (hoisted, they would pin 64 VGPRs)
+      {
+        // K fragments PF MFMAs ahead of their use: an LDS read takes 2-4 MFMA slots to come back, and left to itself
+        // hipcc sinks every read to its MFMA (one fragment register, lgkmcnt(0) before each MFMA) to save registers.
+        // sched_barrier(0) pins the order; the wait counts are still the compiler's.
+        constexpr int PF = CA_ATTN_KPF;
+        bf16x8 kq[PF];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+        for (int i = 0; i < PF; ++i) kq[i] = *(const bf16x8 *)(kbuf + (i >> 3) * 8192 + (k_lane ^ ((i & 7) << 5)));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[0][r] = s[1][r] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const bf16x8 kf = *(const bf16x8 *)(kbuf + kb * 8192 + (k_lane ^ (ks << 5)));
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) {
+          s[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kq[i % PF], qf[i & 7], s[i >> 3], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + PF < 16) {
+            kq[i % PF] = *(const bf16x8 *)(kbuf + ((i + PF) >> 3) * 8192 + (k_lane ^ (((i + PF) & 7) << 5)));
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
       if constexpr (MASKED) {  // key = 64*t + 32*kb + (r&3) + 8*(r>>2) + 4*h
