@@ -310,8 +310,8 @@ __device__ __forceinline__ ca_v8i ca_cat32(bf16x8 lo, bf16x8 hi) {
 }
 
 #ifdef CA_GEMM_STAMP
-// Diagnostic build only (tools/stamp_gemm.py): s_memtime of wave 0 of every workgroup at kernel entry, after the
-// prologue barrier, after the K loop and after the epilogue.
+// Diagnostic build only (tools/stamp_gemm.py, tools/stamp_gemm_persist.py): s_memtime of wave 0 of every tile
+// (index = tile id of the walk) at tile entry, after the prologue barrier, after the K loop and after the epilogue.
 __device__ unsigned long long ca_gemm_dbg[4 * 2048];
 #define CA_GSTAMP(SLOT)                                                                 \
   {                                                                                     \
@@ -319,7 +319,7 @@ __device__ unsigned long long ca_gemm_dbg[4 * 2048];
     __builtin_amdgcn_sched_barrier(0);                                                  \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");        \
     __builtin_amdgcn_sched_barrier(0);                                                  \
-    if (tid == 0 && blockIdx.x < 2048) ca_gemm_dbg[blockIdx.x * 4 + (SLOT)] = ts_;      \
+    if (tid == 0 && bid < 2048) ca_gemm_dbg[bid * 4 + (SLOT)] = ts_;                    \
   }
 #else
 #define CA_GSTAMP(SLOT)
@@ -370,7 +370,10 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
   int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int prob = (lid >= L.ntiles[0]) ? 1 : 0;
   if (prob) lid -= L.ntiles[0];
-  const ca_gemm_problem &P = L.p[prob];
+  // a copy (scalars in SGPRs), not a reference into the by-value kernel argument: with field loads inside the
+  // unrolled epilogue loops hipcc stops promoting the argument and indexes a SCRATCH copy of the whole descriptor
+  // (seen as ScratchSize 392 with zero spills in -Rpass-analysis=kernel-resource-usage)
+  const ca_gemm_problem P = L.p[prob];
   const int MT = L.mt[prob], NT = L.nt[prob];
   const int grp = lid / (GROUP_M * NT);
   const int first_m = grp * GROUP_M;
@@ -794,41 +797,49 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
         for (int j = 0; j < NF; ++j) res[mi][j] = rp[j];
       }
     }
+    // one loop per epilogue kind under a workgroup-uniform branch: with the kind tested per element hipcc
+    // if-converts the test and every bias-only tile pays the 64 v_exp_f32 + 64 v_rcp_f32 per wave and half of a GELU
+    auto rows = [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      const int m = m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
-      uint2 *op = (uint2 *)(outb + ((size_t)m * ldo + nb + col_shift) * 2);
-      const bool first = true;
-      if (epi == CA_EPI_GATE_RESIDUAL && straddle) row_gate(m);
-      uint2 o[NF];
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
+        uint2 *op = (uint2 *)(outb + ((size_t)m * ldo + nb + col_shift) * 2);
+        const bool first = true;
+        if (KIND == CA_EPI_GATE_RESIDUAL && straddle) row_gate(m);
+        uint2 o[NF];
 #pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        float v[4];
+        for (int j = 0; j < NF; ++j) {
+          float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[mi][nj0 + j][r] + bias[4 * j + r];
-          if (epi == CA_EPI_GELU_TANH) v[r] = ca_gelu_tanh(v[r]);
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[mi][nj0 + j][r] + bias[4 * j + r];
+            if (KIND == CA_EPI_GELU_TANH) v[r] = ca_gelu_tanh(v[r]);
+          }
+          if (KIND == CA_EPI_GATE_RESIDUAL) {
+            const bf16x4 r4 = __builtin_bit_cast(bf16x4, res[mi][j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (float)r4[r] + (first ? gate_a[4 * j + r] : gate_b[4 * j + r]) * v[r];
+          }
+          o[j] = make_uint2(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]));
         }
-        if (epi == CA_EPI_GATE_RESIDUAL) {
-          const bf16x4 r4 = __builtin_bit_cast(bf16x4, res[mi][j]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (float)r4[r] + (first ? gate_a[4 * j + r] : gate_b[4 * j + r]) * v[r];
+        if (m < M) {
+          if constexpr (NF == 2) {
+            *(uint4 *)op = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+          } else {
+            op[0] = o[0];
+          }
         }
-        o[j] = make_uint2(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]));
       }
-      if (m < M) {
-        if constexpr (NF == 2) {
-          *(uint4 *)op = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
-        } else {
-          op[0] = o[0];
-        }
-      }
-    }
+    };
+    if (epi == CA_EPI_GELU_TANH) rows(std::integral_constant<int, CA_EPI_GELU_TANH>{});
+    else if (epi == CA_EPI_GATE_RESIDUAL) rows(std::integral_constant<int, CA_EPI_GATE_RESIDUAL>{});
+    else rows(std::integral_constant<int, CA_EPI_BIAS>{});
   };
   half_epilogue(std::integral_constant<int, NL>{}, 0, n0 + wn * 16 * NL + 4 * NL * g);
   half_epilogue(std::integral_constant<int, NHI>{}, NL, n0 + 64 * NL + wn * 16 * NHI + 4 * NHI * g);
 #ifdef CA_GEMM_STAMP
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (CA_GEMM_STAMP != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // 2: stores left in flight (the walk as shipped)
   CA_GSTAMP(3);
 #endif
 }
