@@ -33,7 +33,22 @@ struct GemmLaunch {
   int32_t nt[CA_GEMM_MAX_PROBLEMS];
   int32_t persist_tiles;  // ping-pong kernel: 0 = one workgroup per tile; else total tiles, walked by a CU-sized grid
   int32_t persist_tiles_grid;  // host only: workgroups of the persistent grid (= CUs, a multiple of 8)
+  // ping-pong kernel, tile order: the tiles of a problem's LAST row tile go to the end of the walk when that row tile
+  // is thin (few valid rows), all other ("main") tiles keep the XCD-patch order among themselves
+  int32_t main_total;                        // main tiles of all problems
+  int32_t ntiles_main[CA_GEMM_MAX_PROBLEMS]; // main tiles per problem = mt_main * nt
+  int32_t mt_main[CA_GEMM_MAX_PROBLEMS];     // row tiles in the main order (mt, or mt - 1 with a thin last row tile)
+  int32_t nthin[CA_GEMM_MAX_PROBLEMS];       // thin tiles per problem (nt or 0)
 };
+
+// A last row tile with at most this many valid rows is "thin": its MFMAs on row fragments past M are skipped (the
+// K loop is then paced by the staging and the barriers, about half a tile time), and it is walked last so that it
+// is the thin tiles that spill into a partial last round.  Why: the [concept | text] stream of a 5-item double
+// block has 1300 rows = 5 row tiles + 20 rows; those 20 rows cost every launch of the block one more round of
+// full-price tiles (proj and mlp.2: 1032 tiles = 4.03 rounds -> 5), 9 % of the block (tools/remainder_probe.py).
+#ifndef CA_GEMM_THIN_ROWS
+#define CA_GEMM_THIN_ROWS 128
+#endif
 
 template <int M_REP, int N_REP>
 struct Cfg {
@@ -366,22 +381,38 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
   const int wm = wave >> 2, wn = wave & 3;
   CA_GSTAMP(0);
 
-  const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
-  int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int prob = (lid >= L.ntiles[0]) ? 1 : 0;
-  if (prob) lid -= L.ntiles[0];
+  int prob, mtile, ntile;
+  if (bid < L.main_total) {
+    const int xcd = bid & 7, q8 = L.main_total >> 3, r8 = L.main_total & 7;
+    int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    prob = (lid >= L.ntiles_main[0]) ? 1 : 0;
+    if (prob) lid -= L.ntiles_main[0];
+    const int MT = L.mt_main[prob], NT = L.nt[prob];
+    const int grp = lid / (GROUP_M * NT);
+    const int first_m = grp * GROUP_M;
+    const int gm = min(GROUP_M, MT - first_m);
+    const int in_grp = lid - grp * GROUP_M * NT;
+    mtile = first_m + in_grp % gm;
+    ntile = in_grp / gm;
+  } else {  // thin tiles, after all main tiles: the last row tile of a problem, one tile per column block
+    int u = bid - L.main_total;
+    prob = (u >= L.nthin[0]) ? 1 : 0;
+    if (prob) u -= L.nthin[0];
+    mtile = L.mt[prob] - 1;
+    ntile = u;
+  }
   // a copy (scalars in SGPRs), not a reference into the by-value kernel argument: with field loads inside the
   // unrolled epilogue loops hipcc stops promoting the argument and indexes a SCRATCH copy of the whole descriptor
   // (seen as ScratchSize 392 with zero spills in -Rpass-analysis=kernel-resource-usage)
   const ca_gemm_problem P = L.p[prob];
-  const int MT = L.mt[prob], NT = L.nt[prob];
-  const int grp = lid / (GROUP_M * NT);
-  const int first_m = grp * GROUP_M;
-  const int gm = min(GROUP_M, MT - first_m);
-  const int in_grp = lid - grp * GROUP_M * NT;
-  const int m0 = (first_m + in_grp % gm) * C::BM;
-  const int n0 = (in_grp / gm) * C::BN;
+  const int m0 = mtile * C::BM;
+  const int n0 = ntile * C::BN;
   const int M = P.M;
+  // 16-row fragments of this wave with at least one valid row, in the lo / hi half of the A tile (4 / 4 but in a
+  // last row tile): the MFMAs of the others are skipped
+  const int rows_valid = min(M - m0, C::BM);
+  const int nv_lo = max(0, min(4, (rows_valid - wm * 64 + 15) >> 4));
+  const int nv_hi = max(0, min(4, (rows_valid - 128 - wm * 64 + 15) >> 4));
   const char *Ab = (const char *)P.A;
   const char *Wb = (const char *)P.W;
   const int nk = (int)((uint32_t)P.K * ES / C::ROW_BYTES);
@@ -440,13 +471,14 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
   const int a_off = wm * 64 * C::ROW_BYTES + lane_off;  // + half offset + mi*16 rows
 
   bf16x8 af[4][2], wl[NL][2], wh[NHI][2];
-  auto readA = [&](int buf, int h) {
+  auto readA = [&](int buf, int h, int nv = 4) {  // nv: fragments to read (thin tiles: the valid ones)
     const char *b = smem + buf * C::BUF_BYTES + (h ? C::OFF_AH : C::OFF_AL);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
+      if (mi < nv)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        af[mi][ks] = *(const bf16x8 *)(b + ((a_off + mi * 16 * C::ROW_BYTES) ^ (ks * 64)));
+        for (int ks = 0; ks < 2; ++ks)
+          af[mi][ks] = *(const bf16x8 *)(b + ((a_off + mi * 16 * C::ROW_BYTES) ^ (ks * 64)));
   };
   auto readWL = [&](int buf) {
     const char *b = smem + buf * C::BUF_BYTES + C::OFF_WL;
@@ -466,19 +498,26 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
       for (int ks = 0; ks < 2; ++ks)
         wh[nj][ks] = *(const bf16x8 *)(b + ((w_off + nj * 16 * C::ROW_BYTES) ^ (ks * 64)));
   };
-#define CA_PP_MMA(MI0, NJ0, WF, NW)                                                                         \
+#define CA_PP_MMA_BODY(MI0, NJ0, WF, NW, GUARD)                                                             \
+  if constexpr (FP8) {                                                                                      \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) if (GUARD) _Pragma("unroll") for (int nj = 0; nj < (NW); ++nj) \
+        acc[(MI0) + mi][(NJ0) + nj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                     \
+            ca_cat32(WF[nj][0], WF[nj][1]), ca_cat32(af[mi][0], af[mi][1]), acc[(MI0) + mi][(NJ0) + nj],    \
+            0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                                                            \
+  } else {                                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)       \
+        if (GUARD) _Pragma("unroll") for (int nj = 0; nj < (NW); ++nj) acc[(MI0) + mi][(NJ0) + nj] =        \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nj][ks], af[mi][ks], acc[(MI0) + mi][(NJ0) + nj],    \
+                                                    0, 0, 0);                                               \
+  }
+// NV = valid 16-row fragments of this wave in the A half; only the THIN instantiation of the K loop tests it
+#define CA_PP_MMA(MI0, NJ0, WF, NW, NV)                                                                     \
   {                                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                          \
-    if constexpr (FP8) {                                                                                    \
-      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int nj = 0; nj < (NW); ++nj)  \
-          acc[(MI0) + mi][(NJ0) + nj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                   \
-              ca_cat32(WF[nj][0], WF[nj][1]), ca_cat32(af[mi][0], af[mi][1]), acc[(MI0) + mi][(NJ0) + nj],  \
-              0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                                                          \
+    if constexpr (THIN) {                                                                                   \
+      CA_PP_MMA_BODY(MI0, NJ0, WF, NW, mi < (NV))                                                           \
     } else {                                                                                                \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)     \
-          _Pragma("unroll") for (int nj = 0; nj < (NW); ++nj) acc[(MI0) + mi][(NJ0) + nj] =                 \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nj][ks], af[mi][ks], acc[(MI0) + mi][(NJ0) + nj],  \
-                                                      0, 0, 0);                                             \
+      CA_PP_MMA_BODY(MI0, NJ0, WF, NW, true)                                                                \
     }                                                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                                          \
   }
@@ -514,32 +553,47 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
   CA_PP_SYNC();
   CA_GSTAMP(1);
   if (wm == 1) { CA_PP_SYNC(); }  // stagger: group 1 runs one barrier behind group 0
-  for (int t = 0; t < nk; ++t) {
-    const int b = t & 1;
-    // phase 1
-    readA(b, 0);
-    readWL(b);
-    readWH(b);
-    stageWH(b ^ 1, t + 1);
-    stageA(b ^ 1, 1, t + 1);
-    CA_PP_WAIT_READS();
-    ca_wait_vmcnt<NHI + C::CNT_A>();
-    CA_PP_SYNC();
-    CA_PP_MMA(0, 0, wl, NL);
-    CA_PP_MMA(0, NL, wh, NHI);
-    CA_PP_SYNC();
-    // phase 2
-    readA(b, 1);
-    stageA(b, 0, t + 2);
-    stageWL(b, t + 2);
-    CA_PP_WAIT_READS();
-    ca_wait_vmcnt<C::CNT_A + NL>();
-    CA_PP_SYNC();
-    CA_PP_MMA(4, 0, wl, NL);
-    CA_PP_MMA(4, NL, wh, NHI);
-    CA_PP_SYNC();
-  }
+  // The loop exists twice: as written for full tiles, and for thin tiles (a last row tile with few valid rows,
+  // walked last) with the LDS reads and MFMAs of row fragments past M left out -- same staging, waits and barriers,
+  // so the hand-off rules above hold unchanged; what remains paces at the staging (two DMA round trips per K tile):
+  // about 0.75 of a full tile's time.  (Streaming a <= 32-row tile's operands straight into MFMA registers, four K
+  // tiles in flight and no barrier, was built too: bit-identical, but no faster at K = 3072 and 1.6x slower at
+  // K = 12288 -- 16 rows x 64 bytes per load instruction is a poor pattern for the vector L1.)
+  auto kloop = [&](auto thin_tag) {
+    constexpr bool THIN = decltype(thin_tag)::value;
+    const int rlo = THIN ? nv_lo : 4, rhi = THIN ? nv_hi : 4;
+    for (int t = 0; t < nk; ++t) {
+      const int b = t & 1;
+      // phase 1
+      readA(b, 0, rlo);
+      if (!THIN || rlo + rhi > 0) {
+        readWL(b);
+        readWH(b);
+      }
+      stageWH(b ^ 1, t + 1);
+      stageA(b ^ 1, 1, t + 1);
+      CA_PP_WAIT_READS();
+      ca_wait_vmcnt<NHI + C::CNT_A>();
+      CA_PP_SYNC();
+      CA_PP_MMA(0, 0, wl, NL, rlo);
+      CA_PP_MMA(0, NL, wh, NHI, rlo);
+      CA_PP_SYNC();
+      // phase 2
+      readA(b, 1, rhi);
+      stageA(b, 0, t + 2);
+      stageWL(b, t + 2);
+      CA_PP_WAIT_READS();
+      ca_wait_vmcnt<C::CNT_A + NL>();
+      CA_PP_SYNC();
+      CA_PP_MMA(4, 0, wl, NL, rhi);
+      CA_PP_MMA(4, NL, wh, NHI, rhi);
+      CA_PP_SYNC();
+    }
+  };
+  if (rows_valid <= CA_GEMM_THIN_ROWS) kloop(std::true_type{});
+  else kloop(std::false_type{});
 #else
+  constexpr bool THIN = false;  // (the 4-phase loop has no thin variant)
   // ---- prologue: AL(0) WL(0) WH(0) AH(0) WL(1).  Group 1 executes no retire-wait between this
   // barrier and group 0's first read of W-hi(0), so everything but AH(0), WL(1) must have landed.
   stageA(0, 0, 0);
@@ -562,7 +616,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     stageA(b ^ 1, 0, t + 1);
     CA_PP_WAIT_READS();
     CA_PP_SYNC();
-    CA_PP_MMA(0, 0, wl, NL);
+    CA_PP_MMA(0, 0, wl, NL, nv_lo);
     ca_wait_vmcnt<NL + C::CNT_A>();
     CA_PP_SYNC();
     // phase 2: (A-lo, W-hi)
@@ -570,7 +624,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     stageWH(b ^ 1, t + 1);
     CA_PP_WAIT_READS();
     CA_PP_SYNC();
-    CA_PP_MMA(0, NL, wh, NHI);
+    CA_PP_MMA(0, NL, wh, NHI, nv_lo);
     ca_wait_vmcnt<C::CNT_A + NHI>();
     CA_PP_SYNC();
     // phase 3: (A-hi, W-hi)
@@ -578,13 +632,13 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     stageA(b ^ 1, 1, t + 1);
     CA_PP_WAIT_READS();
     CA_PP_SYNC();
-    CA_PP_MMA(4, NL, wh, NHI);
+    CA_PP_MMA(4, NL, wh, NHI, nv_hi);
     ca_wait_vmcnt<NHI + C::CNT_A>();
     CA_PP_SYNC();
     // phase 4: (A-hi, W-lo); W-lo of tile t+2 goes into the buffer whose W-lo was consumed in phase 1
     stageWL(b, t + 2);
     CA_PP_SYNC();
-    CA_PP_MMA(4, 0, wl, NL);
+    CA_PP_MMA(4, 0, wl, NL, nv_hi);
     ca_wait_vmcnt<C::CNT_A + NL>();
     CA_PP_SYNC();
   }
@@ -1078,6 +1132,14 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
     L.ntiles[1] = 0;
     L.mt[1] = L.nt[1] = 1;
     L.p[1] = L.p[0];
+  }
+  for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i) {  // tile order of the ping-pong kernel: thin last row tiles go last
+    const int rem = i < n_problems ? L.p[i].M % 256 : 0;
+    const int thin = (rem > 0 && rem <= CA_GEMM_THIN_ROWS) ? 1 : 0;
+    L.mt_main[i] = i < n_problems ? L.mt[i] - thin : 1;
+    L.ntiles_main[i] = i < n_problems ? L.mt_main[i] * L.nt[i] : 0;
+    L.nthin[i] = thin ? L.nt[i] : 0;
+    L.main_total += L.ntiles_main[i];
   }
   hipStream_t s = (hipStream_t)stream;
   {  // persistent walk of the tiles when there is more than one round of them (CA_GEMM_PERSIST=0 disables)

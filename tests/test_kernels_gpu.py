@@ -132,6 +132,47 @@ def test_gemm_qkv_norm_rope_epilogue(tail):
                            out2=out2 if tail else None)], L.TILE_PP_256x128)
 
 
+@pytest.mark.parametrize("tile,N", [(L.TILE_PP_256x256, 768), (L.TILE_PP_256x192, 384), (L.TILE_PP_256x128, 256)])
+@pytest.mark.parametrize("rem", [1, 20, 32, 44, 128])
+def test_gemm_thin_last_row_tile_is_bit_identical(tile, N, rem):
+    """A last row tile with few valid rows (<= 128) takes its own copy of the K loop in the ping-pong kernel (the
+    staged loop without the MFMAs and LDS reads of row fragments past M) and is walked last.  Its rows must come out bit for bit as when the same rows sit in a FULL row tile of a longer
+    problem, for every epilogue -- the k order per accumulator is the contract."""
+    K, Mfull = 448, 512
+    a, w, b = rnd(Mfull, K), rnd(N, K, scale=0.1), rnd(N)
+    M = 256 + rem
+    for epi in (L.EPI_BIAS, L.EPI_GELU_TANH):
+        full = ops.linear(a, w, b, epilogue=epi, tile=tile)
+        thin = ops.linear(a[:M], w, b, epilogue=epi, tile=tile)
+        assert torch.equal(thin, full[:M]), f"epilogue {epi}"
+    # gate * x + residual on an fp32 and on a bf16 stream, per-row gate vectors, in place
+    g1, g2 = rnd(N).float(), rnd(N, seed=5).float()
+    for dt in (torch.float32, torch.bfloat16):
+        resid = rnd(Mfull, N).to(dt)
+        xf, xt = resid.clone(), resid[:M].clone()
+        ops.gemm([ops.Gemm(a, w, b, xf, L.EPI_GATE_RESIDUAL, resid=xf, gate=g1, gate2=g2, gate_rows=260)], tile)
+        ops.gemm([ops.Gemm(a[:M], w, b, xt, L.EPI_GATE_RESIDUAL, resid=xt, gate=g1, gate2=g2, gate_rows=260)], tile)
+        assert torch.equal(xt, xf[:M]), f"gated, {dt}"
+    if tile == L.TILE_PP_256x256:  # fused QK-norm + RoPE (N = 768: two heads' worth of q, k, v)
+        table = torch.randn(Mfull, 64, 2, device=DEV)
+        nq, nk = (0.5 + torch.rand(128)).bfloat16().to(DEV), (0.5 + torch.rand(128)).bfloat16().to(DEV)
+        outs = []
+        for rows in (Mfull, M):
+            out = torch.zeros(rows, N, device=DEV, dtype=torch.bfloat16)
+            pre = torch.zeros(rows, N // 3, device=DEV, dtype=torch.bfloat16)
+            ops.gemm([ops.Gemm(a[:rows], w, b, out, L.EPI_QKV_NORM_ROPE, n_split=N, norm_q=nq, norm_k=nk,
+                               rope=table[:rows].contiguous(), q_prerope=pre)], tile)
+            outs.append((out, pre))
+        assert torch.equal(outs[1][0], outs[0][0][:M]) and torch.equal(outs[1][1], outs[0][1][:M])
+    # and two problems in one launch, both with a thin last row tile (the walk puts all thin tiles last)
+    a1, w1, b1 = rnd(rem, K), rnd(N, K, scale=0.1, seed=3), rnd(N, seed=3)
+    o0 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    o1 = torch.empty(rem, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(a[:M], w, b, o0), ops.Gemm(a1, w1, b1, o1, L.EPI_GELU_TANH)], tile)
+    assert torch.equal(o0, ops.linear(a, w, b, tile=tile)[:M])
+    close(o1, torch.nn.functional.gelu(a1.float() @ w1.float().t() + b1.float(), approximate="tanh"), atol=2e-2)
+
+
 def test_gemm_rejects_bad_arguments():
     a, w = rnd(16, 100), rnd(256, 100)
     with pytest.raises(ValueError):
