@@ -715,10 +715,22 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           if (g == 0) part[(hn * 256 + rl) * 4 + wn] = sq;
         }
       }
+      // RoPE values of this lane's 8 rows x 8 columns-in-head: the same for both heads of the tile, fetched ONCE and
+      // before any store of this epilogue.  (Fetched per (row fragment, head) next to their use, every fetch sat
+      // behind the previous fragment's stores -- vmcnt retires in order and counts stores -- sixteen dependent
+      // round trips per tile: the fused epilogue cost 19 us per round of tiles, a bias epilogue 8.)
+      const int cih = wn * 32 + 8 * g;             // column inside the head
+      f32x4 rope0[8], rope1[8];
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1);
+        const float *rp = P.rope + (size_t)m * 128 + cih;  // [64 pairs][cos,sin]; pairs cih/2 .. cih/2+3
+        rope0[mi] = *(const f32x4 *)rp;
+        rope1[mi] = *(const f32x4 *)(rp + 4);
+      }
       __syncthreads();
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn) {
-        const int cih = wn * 32 + 8 * g;           // column inside the head
         const int head_col = (n0 - (is_q ? 0 : hd)) + hn * 128;  // first column of this head in its third
         const bf16x8 s8 = *(const bf16x8 *)(nscale + cih);
 #pragma unroll
@@ -734,8 +746,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           if (is_q && P.q_prerope)
             *(uint4 *)((bf16 *)P.q_prerope + (size_t)m * P.ldp + head_col + cih) =
                 make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
-          const float *rp = P.rope + (size_t)m * 128 + cih;  // [64 pairs][cos,sin]; pairs cih/2 .. cih/2+3
-          const f32x4 r0 = *(const f32x4 *)rp, r1 = *(const f32x4 *)(rp + 4);
+          const f32x4 r0 = rope0[mi], r1 = rope1[mi];
           const float cs[4] = {r0[0], r0[2], r1[0], r1[2]}, sn[4] = {r0[1], r0[3], r1[1], r1[3]};
           float z[8];
 #pragma unroll
