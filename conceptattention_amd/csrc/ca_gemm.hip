@@ -39,6 +39,9 @@ struct GemmLaunch {
   int32_t ntiles_main[CA_GEMM_MAX_PROBLEMS]; // main tiles per problem = mt_main * nt
   int32_t mt_main[CA_GEMM_MAX_PROBLEMS];     // row tiles in the main order (mt, or mt - 1 with a thin last row tile)
   int32_t nthin[CA_GEMM_MAX_PROBLEMS];       // thin tiles per problem (nt or 0)
+  // thin-row kernel (a last row tile of <= 32 rows under the 256x256 bf16 ping-pong tile): 32 x 128 tiles
+  int32_t thin_row0[CA_GEMM_MAX_PROBLEMS];   // first row of the problem's thin part
+  int32_t thin_nt[CA_GEMM_MAX_PROBLEMS];     // its 128-column tiles (N / 128), 0 = none
 };
 
 // A last row tile with at most this many valid rows is "thin": its MFMAs on row fragments past M are skipped (the
@@ -707,7 +710,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
             for (int r = 0; r < 4; ++r) {
               const float v = acc[mi][hn * 2 + j][r] + bias[4 * j + r];
               x[mi][hn][4 * j + r] = v;
-              sq += v * v;
+              sq = __builtin_fmaf(v, v, sq);  // (explicit: the thin-row kernel must round as this one does)
             }
           sq += __shfl_xor(sq, 16);
           sq += __shfl_xor(sq, 32);
@@ -739,7 +742,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           const int m = m0 + rl;
           if (m >= M) continue;
           const f32x4 p4 = *(const f32x4 *)(part + (hn * 256 + rl) * 4);
-          const float rrms = rsqrtf((p4[0] + p4[1] + p4[2] + p4[3]) * (1.0f / 128.0f) + 1e-6f);
+          const float rrms = rsqrtf(__builtin_fmaf(p4[0] + p4[1] + p4[2] + p4[3], 1.0f / 128.0f, 1e-6f));
           float y[8];
 #pragma unroll
           for (int t = 0; t < 8; ++t) y[t] = x[mi][hn][t] * rrms * (float)s8[t];
@@ -751,8 +754,8 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           float z[8];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            z[2 * i] = cs[i] * y[2 * i] - sn[i] * y[2 * i + 1];
-            z[2 * i + 1] = sn[i] * y[2 * i] + cs[i] * y[2 * i + 1];
+            z[2 * i] = __builtin_fmaf(cs[i], y[2 * i], -(sn[i] * y[2 * i + 1]));
+            z[2 * i + 1] = __builtin_fmaf(sn[i], y[2 * i], cs[i] * y[2 * i + 1]);
           }
           *(uint4 *)(outb + ((size_t)m * ldo + n0 + hn * 128 + cih) * 2) =
               make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
@@ -844,7 +847,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               v[r] = acc[mi][nj0 + j][r] + bias[4 * j + r];
-              if (gated) v[r] = r32[mq][j][r] + (first ? gate_a[4 * j + r] : gate_b[4 * j + r]) * v[r];
+              if (gated) v[r] = __builtin_fmaf(first ? gate_a[4 * j + r] : gate_b[4 * j + r], v[r], r32[mq][j][r]);
             }
             if (m < M) op[j] = v;
           }
@@ -884,7 +887,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           if (KIND == CA_EPI_GATE_RESIDUAL) {
             const bf16x4 r4 = __builtin_bit_cast(bf16x4, res[mi][j]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (float)r4[r] + (first ? gate_a[4 * j + r] : gate_b[4 * j + r]) * v[r];
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(first ? gate_a[4 * j + r] : gate_b[4 * j + r], v[r], (float)r4[r]);
           }
           o[j] = make_uint2(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]));
         }
@@ -924,6 +927,240 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
   } else {
     ca_gemm_pp_tile<NL, NHI, FP8>(L, smem, blockIdx.x, gridDim.x);
   }
+}
+
+// =============================================================================================
+// Thin-row kernel: the last row tile of a problem when it has at most 32 rows (the 5 x 4 concept rows that the
+// [concept | text] stream of a 5-item double block carries past its 5 full row tiles; the 4 rows a single item
+// leaves over).  As 256-column tiles of the ping-pong kernel those rows cost a launch 12 full-price tiles -- one
+// CU streams 256 weight rows per tile through its vector L1 whatever the row count -- and with them a fifth round
+// (section "the 20 rows" of DESIGN.md).  Here they are 32 x 128 tiles, one workgroup of 4 waves each, so the weight
+// rows of the thin part are spread over N / 128 CUs; a wave owns 32 columns = the two 16-column fragments and the
+// weight-row permutation of a ping-pong wave, so a lane again holds 8 contiguous columns of row lane&15 and the
+// epilogues are the ping-pong kernel's, fragment for fragment.  Same MFMA, same operand roles, same k order per
+// accumulator and the same expression order in every epilogue: results are bit-identical to the same rows inside a
+// full ping-pong tile (tests/test_kernels_gpu.py::test_gemm_thin_last_row_tile_is_bit_identical).
+// Staging: a K tile is 32 activation rows + 128 weight rows of 128 bytes = 20 pieces of 1 KB by LDS-DMA, 5 per wave,
+// into a ring of 4 slots; the DMA of tile t+3 is issued right after the barrier of iteration t (its slot held tile
+// t-1, read before that barrier) and every iteration opens with vmcnt(10) = "all but my two youngest tiles have
+// landed" followed by the barrier that publishes tile t: one barrier per K tile, three tiles in flight.
+constexpr int THIN_M = 32, THIN_N = 128, THIN_STAGE = (THIN_M + THIN_N) * 128, THIN_SLOTS = 4;
+constexpr int THIN_LDS = THIN_SLOTS * THIN_STAGE;
+
+__global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = 32-column group
+  int u = blockIdx.x;
+  const int prob = (u >= L.thin_nt[0]) ? 1 : 0;
+  if (prob) u -= L.thin_nt[0];
+  const ca_gemm_problem P = L.p[prob];
+  const int m0 = L.thin_row0[prob], n0 = u * THIN_N, M = P.M;
+  const char *Ab = (const char *)P.A;
+  const char *Wb = (const char *)P.W;
+  const int nk = P.K / 64;
+
+  // ---- staging sources: piece q = 5*wave + i covers LDS rows 8q .. 8q+7 (rows 0..31: A, 32..159: W)
+  const char *src[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int rr = 8 * (5 * wn + i) + (lane >> 3);
+    if (rr < THIN_M) {
+      const int c = (lane & 7) ^ ((rr >> 1) & 7);
+      src[i] = Ab + (size_t)min(m0 + rr, M - 1) * P.lda * 2 + c * 16;
+    } else {
+      const int wr = rr - THIN_M;  // LDS row of the W image: wave wr/32, fragment order as in the ping-pong kernel
+      const int c = (lane & 7) ^ ((wr >> 1) & 7);
+      const int wloc = wr & 31;
+      const int j = wloc >> 4, a = (wloc >> 2) & 3, b = wloc & 3;
+      src[i] = Wb + (size_t)(n0 + (wr - wloc) + 8 * a + 4 * j + b) * P.ldw * 2 + c * 16;
+    }
+  }
+  auto stage = [&](int slot, int kt) {
+    const int kb = min(kt, nk - 1) * 128;  // (tiles past the end re-stage the last one into a slot nobody reads)
+    char *base = smem + slot * THIN_STAGE + 5 * wn * 1024;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) ca_glds16(src[i] + kb, base + i * 1024);
+  };
+  const int lane_off = (lane & 15) * 128 + ((((lane >> 4) ^ ((lane & 15) >> 1)) & 7) << 4);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  stage(1, 1);
+  stage(2, 2);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    stage((t + 3) & 3, t + 3);
+    const char *sb = smem + (t & 3) * THIN_STAGE;
+    bf16x8 af[2][2], wf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) af[mi][ks] = *(const bf16x8 *)(sb + ((mi * 16 * 128 + lane_off) ^ (ks * 64)));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wf[j][ks] = *(const bf16x8 *)(sb + (((THIN_M + wn * 32 + j * 16) * 128 + lane_off) ^ (ks * 64)));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[mi][ks], acc[mi][j], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // no LDS-DMA outstanding, every wave done reading: the LDS is free for the row sums
+
+  // ---- epilogues: acc[mi][j][r] = C[m][n], m = m0 + 16*mi + (lane&15), n = n0 + wn*32 + 8*(lane>>4) + 4*j + r
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nb = n0 + wn * 32 + 8 * g;
+  int epi = P.epilogue;
+  char *outb = (char *)P.out;
+  int ldo = P.ldc, col_shift = 0;
+  float bias[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) bias[t] = 0.f;
+  if (P.bias) {
+    const bf16x8 b8 = *(const bf16x8 *)((const bf16 *)P.bias + nb);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bias[t] = (float)b8[t];
+  }
+  if (epi == CA_EPI_QKV_NORM_ROPE && n0 < (P.n_split / 3) * 2) {  // this tile = one head of q or k
+    const int hd = P.n_split / 3;
+    const bool is_q = n0 < hd;
+    const bf16 *nscale = (const bf16 *)(is_q ? P.norm_q : P.norm_k);
+    float *part = (float *)smem;  // [32 rows][4 column-waves]
+    float x[2][8];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[mi][j][r] + bias[4 * j + r];
+          x[mi][4 * j + r] = v;
+          sq = __builtin_fmaf(v, v, sq);  // (explicit: the thin-row kernel must round as this one does)
+        }
+      sq += __shfl_xor(sq, 16);
+      sq += __shfl_xor(sq, 32);
+      if (g == 0) part[(16 * mi + l15) * 4 + wn] = sq;
+    }
+    const int cih = wn * 32 + 8 * g;
+    f32x4 rope0[2], rope1[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const float *rp = P.rope + (size_t)min(m0 + 16 * mi + l15, M - 1) * 128 + cih;
+      rope0[mi] = *(const f32x4 *)rp;
+      rope1[mi] = *(const f32x4 *)(rp + 4);
+    }
+    __syncthreads();
+    const int head_col = n0 - (is_q ? 0 : hd);
+    const bf16x8 s8 = *(const bf16x8 *)(nscale + cih);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + 16 * mi + l15;
+      if (m >= M) continue;
+      const f32x4 p4 = *(const f32x4 *)(part + (16 * mi + l15) * 4);
+      const float rrms = rsqrtf(__builtin_fmaf(p4[0] + p4[1] + p4[2] + p4[3], 1.0f / 128.0f, 1e-6f));
+      float y[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) y[t] = x[mi][t] * rrms * (float)s8[t];
+      if (is_q && P.q_prerope)
+        *(uint4 *)((bf16 *)P.q_prerope + (size_t)m * P.ldp + head_col + cih) =
+            make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+      const f32x4 r0 = rope0[mi], r1 = rope1[mi];
+      const float cs[4] = {r0[0], r0[2], r1[0], r1[2]}, sn[4] = {r0[1], r0[3], r1[1], r1[3]};
+      float z[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        z[2 * i] = __builtin_fmaf(cs[i], y[2 * i], -(sn[i] * y[2 * i + 1]));
+        z[2 * i + 1] = __builtin_fmaf(sn[i], y[2 * i], cs[i] * y[2 * i + 1]);
+      }
+      *(uint4 *)(outb + ((size_t)m * ldo + n0 + cih) * 2) =
+          make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
+    }
+    return;
+  }
+  if (epi == CA_EPI_QKV_NORM_ROPE) epi = CA_EPI_SPLIT_GELU;
+  if (epi == CA_EPI_SPLIT_GELU) {
+    if (n0 >= P.n_split) {
+      epi = CA_EPI_GELU_TANH;
+      outb = (char *)P.out2;
+      ldo = P.ld2;
+      col_shift = -P.n_split;
+    } else {
+      epi = CA_EPI_BIAS;
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + 16 * mi + l15;
+    if (m >= M) continue;
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = acc[mi][t >> 2][t & 3] + bias[t];
+    if (epi == CA_EPI_GELU_TANH) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = ca_gelu_tanh(v[t]);
+    }
+    if (epi == CA_EPI_GATE_RESIDUAL) {
+      const float *gr = ca_gate_of(P, m) + nb;
+      const f32x4 g0 = *(const f32x4 *)gr, g1 = *(const f32x4 *)(gr + 4);
+      const float gt[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+      if (P.out_f32) {
+        const f32x4 *rp = (const f32x4 *)((const char *)P.resid + ((size_t)m * P.ldr + nb) * 4);
+        const f32x4 ra = rp[0], rb = rp[1];
+        const float res[8] = {ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = __builtin_fmaf(gt[t], v[t], res[t]);
+      } else {
+        const bf16x8 r8 = *(const bf16x8 *)((const char *)P.resid + ((size_t)m * P.ldr + nb) * 2);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = __builtin_fmaf(gt[t], v[t], (float)r8[t]);
+      }
+    }
+    if (P.out_f32 && (epi == CA_EPI_GATE_RESIDUAL || epi == CA_EPI_BIAS)) {
+      f32x4 *op = (f32x4 *)(outb + ((size_t)m * ldo + nb + col_shift) * 4);
+      op[0] = f32x4{v[0], v[1], v[2], v[3]};
+      op[1] = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      *(uint4 *)(outb + ((size_t)m * ldo + nb + col_shift) * 2) =
+          make_uint4(ca_pack2(v[0], v[1]), ca_pack2(v[2], v[3]), ca_pack2(v[4], v[5]), ca_pack2(v[6], v[7]));
+    }
+  }
+}
+
+int launch_thin(const GemmLaunch &L, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
+  const unsigned long long dev_bit = ca_device_bit();
+  if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
+    hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       THIN_LDS);
+    if (e != hipSuccess) {
+      ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", THIN_LDS, hipGetErrorString(e));
+      return CA_ERR_LAUNCH;
+    }
+    attr_done.fetch_or(dev_bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(ca_gemm_thin_kernel, dim3(L.thin_nt[0] + L.thin_nt[1]), dim3(256), THIN_LDS, stream, L);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ca_set_error("ca_gemm_bf16: thin-row launch failed: %s", hipGetErrorString(e));
+    return CA_ERR_LAUNCH;
+  }
+  return CA_OK;
 }
 
 template <int NL, int NHI, bool FP8 = false>
@@ -1144,14 +1381,26 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
     L.mt[1] = L.nt[1] = 1;
     L.p[1] = L.p[0];
   }
+  static const int thin_kernel_env = [] {
+    const char *e = getenv("CA_GEMM_THIN_KERNEL");  // 0: thin rows stay 256-column tiles of the ping-pong walk (A/B aid)
+    return e ? atoi(e) : 1;
+  }();
+  int total_pp = 0;
   for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i) {  // tile order of the ping-pong kernel: thin last row tiles go last
     const int rem = i < n_problems ? L.p[i].M % 256 : 0;
     const int thin = (rem > 0 && rem <= CA_GEMM_THIN_ROWS) ? 1 : 0;
+    // <= 32 rows under the bf16 256x256 tile: their own launch of 32 x 128 tiles instead (ca_gemm_thin_kernel)
+    const bool own = thin && rem <= THIN_M && !fp8 && tile == CA_TILE_PP_256x256 && thin_kernel_env;
     L.mt_main[i] = i < n_problems ? L.mt[i] - thin : 1;
     L.ntiles_main[i] = i < n_problems ? L.mt_main[i] * L.nt[i] : 0;
-    L.nthin[i] = thin ? L.nt[i] : 0;
+    L.nthin[i] = (thin && !own) ? L.nt[i] : 0;
+    L.thin_row0[i] = own ? (L.mt[i] - 1) * 256 : 0;
+    L.thin_nt[i] = own ? L.p[i].N / THIN_N : 0;
     L.main_total += L.ntiles_main[i];
+    total_pp += L.ntiles_main[i] + L.nthin[i];
   }
+  const bool pp_tile = fp8 || tile == CA_TILE_PP_256x256 || tile == CA_TILE_PP_256x192 || tile == CA_TILE_PP_256x128;
+  if (pp_tile) total = total_pp;  // (the simple kernel keeps every row tile)
   hipStream_t s = (hipStream_t)stream;
   {  // persistent walk of the tiles when there is more than one round of them (CA_GEMM_PERSIST=0 disables)
     static const int persist_env = [] {
@@ -1172,6 +1421,13 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
     }
   }
   if (fp8) return launch_pp<2, 2, true>(L, total, s);
+  if (tile == CA_TILE_PP_256x256 && L.thin_nt[0] + L.thin_nt[1] > 0) {
+    if (total > 0) {
+      const int rc = launch_pp<2, 2>(L, total, s);
+      if (rc != CA_OK) return rc;
+    }
+    return launch_thin(L, s);
+  }
   switch (tile) {
     case CA_TILE_PP_256x256: return launch_pp<2, 2>(L, total, s);
     case CA_TILE_PP_256x192: return launch_pp<2, 1>(L, total, s);
