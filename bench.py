@@ -333,7 +333,7 @@ def main():
             roof.update(kernel=names.get(tile, str(tile)), launches=n, avg_launch_us=sec / n * 1e6,
                         flops_per_launch=fl / n, achieved=fl / sec / 1e12,
                         timed_on=f"last group of {n_last} work items of rank 0 (one forward per diffusion step)",
-                        launch_is="one ca_gemm_bf16 call: the ping-pong launch plus, for a <= 32-row last row tile, "
+                        launch_is="one ca_gemm_bf16 call: the ping-pong launch plus, for a thin last row tile, "
                                   "its thin-row launch (ca_gemm_thin_kernel); rocprofv3 lists the two kernels separately",
                         share_of_that_group=sec / (elapsed * n_last / max(len(timed_items), 1)))
         else:

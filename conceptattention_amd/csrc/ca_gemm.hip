@@ -39,7 +39,7 @@ struct GemmLaunch {
   int32_t ntiles_main[CA_GEMM_MAX_PROBLEMS]; // main tiles per problem = mt_main * nt
   int32_t mt_main[CA_GEMM_MAX_PROBLEMS];     // row tiles in the main order (mt, or mt - 1 with a thin last row tile)
   int32_t nthin[CA_GEMM_MAX_PROBLEMS];       // thin tiles per problem (nt or 0)
-  // thin-row kernel (a last row tile of <= 32 rows under the 256x256 bf16 ping-pong tile): 32 x 128 tiles
+  // thin-row kernel (a thin last row tile under the 256x256 bf16 ping-pong tile): 32 x 128 tiles
   int32_t thin_row0[CA_GEMM_MAX_PROBLEMS];   // first row of the problem's thin part
   int32_t thin_nt[CA_GEMM_MAX_PROBLEMS];     // its 128-column tiles (N / 128), 0 = none
 };
@@ -930,9 +930,9 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
 }
 
 // =============================================================================================
-// Thin-row kernel: the last row tile of a problem when it has at most 32 rows (the 5 x 4 concept rows that the
-// [concept | text] stream of a 5-item double block carries past its 5 full row tiles; the 4 rows a single item
-// leaves over).  As 256-column tiles of the ping-pong kernel those rows cost a launch 12 full-price tiles -- one
+// Thin-row kernel: the last row tile of a problem when it is thin (<= CA_GEMM_THIN_ROWS rows: the 5 x 4 concept rows
+// that the [concept | text] stream of a 5-item double block carries past its 5 full row tiles; the 4 rows a single
+// item leaves over), 32 rows per workgroup (grid y).  As 256-column tiles of the ping-pong kernel those rows cost a launch 12 full-price tiles -- one
 // CU streams 256 weight rows per tile through its vector L1 whatever the row count -- and with them a fifth round
 // (section "the 20 rows" of DESIGN.md).  Here they are 32 x 128 tiles, one workgroup of 4 waves each, so the weight
 // rows of the thin part are spread over N / 128 CUs; a wave owns 32 columns = the two 16-column fragments and the
@@ -956,7 +956,8 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
   const int prob = (u >= L.thin_nt[0]) ? 1 : 0;
   if (prob) u -= L.thin_nt[0];
   const ca_gemm_problem P = L.p[prob];
-  const int m0 = L.thin_row0[prob], n0 = u * THIN_N, M = P.M;
+  const int m0 = L.thin_row0[prob] + THIN_M * (int)blockIdx.y, n0 = u * THIN_N, M = P.M;
+  if (m0 >= M) return;  // (two problems with different thin row counts share a grid: whole workgroup)
   const char *Ab = (const char *)P.A;
   const char *Wb = (const char *)P.W;
   const int nk = P.K / 64;
@@ -1154,7 +1155,10 @@ int launch_thin(const GemmLaunch &L, hipStream_t stream) {
     }
     attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(ca_gemm_thin_kernel, dim3(L.thin_nt[0] + L.thin_nt[1]), dim3(256), THIN_LDS, stream, L);
+  int groups = 1;  // 32-row groups of the longest thin part
+  for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i)
+    if (L.thin_nt[i]) groups = max(groups, (L.p[i].M - L.thin_row0[i] + THIN_M - 1) / THIN_M);
+  hipLaunchKernelGGL(ca_gemm_thin_kernel, dim3(L.thin_nt[0] + L.thin_nt[1], groups), dim3(256), THIN_LDS, stream, L);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ca_set_error("ca_gemm_bf16: thin-row launch failed: %s", hipGetErrorString(e));
@@ -1389,8 +1393,9 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
   for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i) {  // tile order of the ping-pong kernel: thin last row tiles go last
     const int rem = i < n_problems ? L.p[i].M % 256 : 0;
     const int thin = (rem > 0 && rem <= CA_GEMM_THIN_ROWS) ? 1 : 0;
-    // <= 32 rows under the bf16 256x256 tile: their own launch of 32 x 128 tiles instead (ca_gemm_thin_kernel)
-    const bool own = thin && rem <= THIN_M && !fp8 && tile == CA_TILE_PP_256x256 && thin_kernel_env;
+    // under the bf16 256x256 tile: their own launch of 32 x 128 tiles instead (ca_gemm_thin_kernel), one grid row
+    // per 32 rows
+    const bool own = thin && !fp8 && tile == CA_TILE_PP_256x256 && thin_kernel_env;
     L.mt_main[i] = i < n_problems ? L.mt[i] - thin : 1;
     L.ntiles_main[i] = i < n_problems ? L.mt_main[i] * L.nt[i] : 0;
     L.nthin[i] = (thin && !own) ? L.nt[i] : 0;

@@ -135,9 +135,9 @@ def test_gemm_qkv_norm_rope_epilogue(tail):
 @pytest.mark.parametrize("tile,N", [(L.TILE_PP_256x256, 768), (L.TILE_PP_256x192, 384), (L.TILE_PP_256x128, 256)])
 @pytest.mark.parametrize("rem", [1, 20, 32, 44, 128])
 def test_gemm_thin_last_row_tile_is_bit_identical(tile, N, rem):
-    """A last row tile with few valid rows leaves the ordinary tile walk: <= 32 rows under the 256x256 tile go to the
-    thin-row kernel (32 x 128 tiles, its own launch), <= 128 rows otherwise take a copy of the ping-pong K loop
-    without the MFMAs and LDS reads of row fragments past M and are walked last.  Its rows must come out bit for bit as when the same rows sit in a FULL row tile of a longer
+    """A last row tile with few valid rows (<= 128) leaves the ordinary tile walk: under the bf16 256x256 tile it goes
+    to the thin-row kernel (32 x 128 tiles, its own launch), otherwise it takes a copy of the ping-pong K loop
+    without the MFMAs and LDS reads of row fragments past M and is walked last.  Its rows must come out bit for bit as when the same rows sit in a FULL row tile of a longer
     problem, for every epilogue -- the k order per accumulator is the contract."""
     K, Mfull = 448, 512
     a, w, b = rnd(Mfull, K), rnd(N, K, scale=0.1), rnd(N)
