@@ -51,7 +51,11 @@ int ca_check_device(void);
  * Up to CA_GEMM_MAX_PROBLEMS problems share one launch (image stream + text/concept stream of a
  * double block), so the grid fills all 256 CUs.
  * Requirements: K % 64 == 0, N % tile_n == 0, lda/ldw/ldc/ldr/ld2 % 8 == 0, 16-byte aligned
- * pointers.  M is arbitrary (rows are masked).
+ * pointers.  M is arbitrary (rows are masked).  A call is one kernel launch on `stream`, or two:
+ * under the 256x256 ping-pong tile a problem's last row tile with at most 128 rows (M % 256 in
+ * [1, 128]: the concept rows a [concept | text] stream carries past its full row tiles) runs as
+ * 32 x 128 tiles of a second kernel queued right behind the first (bit-identical results; set
+ * CA_GEMM_THIN_KERNEL=0 in the environment to keep those rows in the first kernel's tile walk).
  */
 enum {
   CA_EPI_BIAS = 0,          /* out = acc + bias */

@@ -46,7 +46,17 @@ def fp8():
     return o
 
 
-cases = {"attention": attn, "mlp0 (grouped, persistent)": mlp0, "linear2 (K=15360)": linear2, "fp8 gemm": fp8}
+at, wt = rnd(1300, 12288), rnd(3072, 12288, scale=0.02)
+xt0 = torch.randn(1300, 3072, device=dev)
+
+
+def thin_rows():  # 5 full row tiles in the ping-pong walk + 20 rows in the thin-row kernel (4-slot LDS-DMA ring, K = 12288)
+    x = xt0.clone()
+    ops.gemm([ops.Gemm(at, wt, None, x, L.EPI_GATE_RESIDUAL, resid=x, gate=gate)], L.TILE_PP_256x256)
+    return x
+
+
+cases = {"thin rows (mlp.2 shape)": thin_rows, "attention": attn, "mlp0 (grouped, persistent)": mlp0, "linear2 (K=15360)": linear2, "fp8 gemm": fp8}
 first = {name: fn() for name, fn in cases.items()}
 torch.cuda.synchronize()
 bad = {name: 0 for name in cases}
