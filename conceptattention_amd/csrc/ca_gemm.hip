@@ -330,14 +330,14 @@ __device__ __forceinline__ ca_v8i ca_cat32(bf16x8 lo, bf16x8 hi) {
 #ifdef CA_GEMM_STAMP
 // Diagnostic build only (tools/stamp_gemm.py, tools/stamp_gemm_persist.py): s_memtime of wave 0 of every tile
 // (index = tile id of the walk) at tile entry, after the prologue barrier, after the K loop and after the epilogue.
-__device__ unsigned long long ca_gemm_dbg[4 * 2048];
+__device__ unsigned long long ca_gemm_dbg[8 * 2048];  // 8 stamps per tile: 0-3 the tile, 4-7 inside the fused qkv epilogue
 #define CA_GSTAMP(SLOT)                                                                 \
   {                                                                                     \
     unsigned long long ts_;                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                  \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");        \
     __builtin_amdgcn_sched_barrier(0);                                                  \
-    if (tid == 0 && bid < 2048) ca_gemm_dbg[bid * 4 + (SLOT)] = ts_;                    \
+    if (tid == 0 && bid < 2048) ca_gemm_dbg[bid * 8 + (SLOT)] = ts_;                    \
   }
 #else
 #define CA_GSTAMP(SLOT)
@@ -647,7 +647,12 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
   }
 #endif
   if (wm == 0) { CA_PP_SYNC(); }
-  ca_wait_vmcnt<0>();  // no LDS-DMA may be outstanding when the workgroup retires
+  // No LDS-DMA may be outstanding when the workgroup retires or the epilogue reuses the LDS.  Through the BUILTIN
+  // (0x0F70 = vmcnt 0): hipcc's wait-count pass does not see waits in inline asm, keeps believing that the loop's
+  // global_load_lds are in flight, and then puts an s_waitcnt vmcnt(0) in front of every LDS read of the epilogue --
+  // which there waits for the acknowledgement of every global store issued so far (the fused QK-norm + RoPE epilogue
+  // read its row sums fragment by fragment between stores: 940 cycles per fragment).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   CA_GSTAMP(2);
   if constexpr (FP8) {
     // dequantise: acc[m][n] *= a_scale[m] * w_scale[n] (column order of the accumulators: see below)
@@ -718,10 +723,11 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           if (g == 0) part[(hn * 256 + rl) * 4 + wn] = sq;
         }
       }
-      // RoPE values of this lane's 8 rows x 8 columns-in-head: the same for both heads of the tile, fetched ONCE and
-      // before any store of this epilogue.  (Fetched per (row fragment, head) next to their use, every fetch sat
-      // behind the previous fragment's stores -- vmcnt retires in order and counts stores -- sixteen dependent
-      // round trips per tile: the fused epilogue cost 19 us per round of tiles, a bias epilogue 8.)
+      // RoPE values of this lane's 8 rows x 8 columns-in-head (the same for both heads of the tile) and the norm
+      // scales: every global load of this epilogue is issued here, before its first store, and waited for ONCE below.
+      // (Loaded next to their use, each load -- and, through hipcc's vmcnt(0) in front of every use, each fragment --
+      // waited for the acknowledgement of the previous fragment's stores: vmcnt retires in order and counts stores.
+      // Stamps of wave 0, per head of 8 fragments: 7500 -> 3700 cycles.)
       const int cih = wn * 32 + 8 * g;             // column inside the head
       f32x4 rope0[8], rope1[8];
 #pragma unroll
@@ -731,11 +737,18 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
         rope0[mi] = *(const f32x4 *)rp;
         rope1[mi] = *(const f32x4 *)(rp + 4);
       }
+      const bf16x8 s8 = *(const bf16x8 *)(nscale + cih);  // norm scales of this lane's 8 columns-in-head (both heads)
+      CA_GSTAMP(4);
       __syncthreads();
+      // every load of this epilogue has been issued: wait for them HERE, once, through the builtin.  Otherwise hipcc
+      // covers each use of the RoPE values below with s_waitcnt vmcnt(0), which by then also waits for the stores of
+      // the fragments before it (vmcnt counts stores and retires in order).
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      CA_GSTAMP(5);
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn) {
+        if (hn == 1) { CA_GSTAMP(6); }
         const int head_col = (n0 - (is_q ? 0 : hd)) + hn * 128;  // first column of this head in its third
-        const bf16x8 s8 = *(const bf16x8 *)(nscale + cih);
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
           const int rl = (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15);
@@ -1457,6 +1470,6 @@ extern "C" int ca_gemm_fp8(const ca_gemm_problem *problems, int32_t n_problems, 
 
 #ifdef CA_GEMM_STAMP
 extern "C" int ca_debug_read_gemm(unsigned long long *out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_gemm_dbg), sizeof(unsigned long long) * 4 * 2048);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_gemm_dbg), sizeof(unsigned long long) * 8 * 2048);
 }
 #endif

@@ -27,6 +27,9 @@ def run(M, N, K, epi, name):
     b = torch.randn(N, device="cuda").bfloat16()
     o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     kw = dict(resid=o, gate=torch.randn(N, device="cuda")) if epi == L.EPI_GATE_RESIDUAL else {}
+    if epi == L.EPI_QKV_NORM_ROPE:
+        s128 = torch.ones(128, device="cuda", dtype=torch.bfloat16)
+        kw = dict(n_split=N, norm_q=s128, norm_k=s128, rope=torch.randn(M, 64, 2, device="cuda"))
     for _ in range(3):
         ops.gemm([ops.Gemm(a, w, b, o, epi, **kw)], L.TILE_PP_256x256)
     torch.cuda.synchronize()
@@ -58,5 +61,6 @@ def run(M, N, K, epi, name):
 
 
 run(13068, 9216, 3072, L.EPI_BIAS, "qkv x3")
+run(13056, 6144, 3072, L.EPI_QKV_NORM_ROPE, "q,k thirds x3, fused norm + rope")
 pass
 run(8712, 12288, 3072, L.EPI_GELU_TANH, "mlp0 x2")
