@@ -788,19 +788,49 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
       epi = CA_EPI_BIAS;
     }
   }
-  auto half_epilogue = [&](auto nfrag_tag, int nj0, int nb) {
+  // Bias and gate vectors of BOTH column halves are fetched here, before the first store of the epilogue, and waited
+  // for once through the builtin.  The stores below are predicated (m < M), which leaves hipcc's wait-count pass
+  // unable to count them: while any load is pending in its books it covers the next use with s_waitcnt vmcnt(0), and
+  // after the first store that is a wait for the store's acknowledgement (fetched per half, the second half's bias
+  // waited for all of the first half's stores): -0.5...-0.8 % per launch.  (One vmcnt(0) per half remains, right after
+  // its first predicated store; a build with unpredicated stores has none and is no faster.)
+  const int nb_lo = n0 + wn * 16 * NL + 4 * NL * g, nb_hi = n0 + 64 * NL + wn * 16 * NHI + 4 * NHI * g;
+  bf16x4 braw_lo[NL], braw_hi[NHI];
+  f32x4 graw_lo[NL], graw_hi[NHI];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    braw_lo[j] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    graw_lo[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < NHI; ++j) {
+    braw_hi[j] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    graw_hi[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (P.bias) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) braw_lo[j] = *(const bf16x4 *)((const bf16 *)P.bias + nb_lo + 4 * j);
+#pragma unroll
+    for (int j = 0; j < NHI; ++j) braw_hi[j] = *(const bf16x4 *)((const bf16 *)P.bias + nb_hi + 4 * j);
+  }
+  if (epi == CA_EPI_GATE_RESIDUAL) {
+    const float *gv = ca_gate_of(P, m0);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) graw_lo[j] = *(const f32x4 *)(gv + nb_lo + 4 * j);
+#pragma unroll
+    for (int j = 0; j < NHI; ++j) graw_hi[j] = *(const f32x4 *)(gv + nb_hi + 4 * j);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of this tile has been stored yet
+  auto half_epilogue = [&](auto nfrag_tag, int nj0, int nb, const auto &braw, const auto &graw) {
     constexpr int NF = decltype(nfrag_tag)::value;
     float bias[4 * NF], gate_a[4 * NF], gate_b[4 * NF];
 #pragma unroll
-    for (int t = 0; t < 4 * NF; ++t) bias[t] = gate_a[t] = gate_b[t] = 0.f;
-    if (P.bias) {
+    for (int j = 0; j < NF; ++j)
 #pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const bf16x4 b4 = *(const bf16x4 *)((const bf16 *)P.bias + nb + 4 * j);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[4 * j + r] = (float)b4[r];
+      for (int r = 0; r < 4; ++r) {
+        bias[4 * j + r] = (float)braw[j][r];
+        gate_a[4 * j + r] = gate_b[4 * j + r] = graw[j][r];
       }
-    }
     // Gates: the usual tile lies inside one work item and one row range, so its rows share ONE gate vector, loaded
     // once (gate_a; `straddle` false).  A tile that spans items or the gate_rows boundary (the concept | text tile)
     // fetches the vector per row fragment instead.
@@ -811,13 +841,6 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
       const int m_hi = min(m0 + C::BM, M) - 1;
       const float *g_lo = ca_gate_of(P, m0);
       straddle = (m0 < P.gate_rows) != (m_hi < P.gate_rows) || g_lo != ca_gate_of(P, m_hi);  // workgroup-uniform
-      const float *g1 = g_lo + nb;
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const f32x4 ga = *(const f32x4 *)(g1 + 4 * j);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gate_a[4 * j + r] = gate_b[4 * j + r] = ga[r];
-      }
     }
     auto row_gate = [&](int m) {  // straddling tile only: this lane's row m has its own vector
       const float *gr = ca_gate_of(P, min(m, M - 1)) + nb;
@@ -917,8 +940,8 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     else if (epi == CA_EPI_GATE_RESIDUAL) rows(std::integral_constant<int, CA_EPI_GATE_RESIDUAL>{});
     else rows(std::integral_constant<int, CA_EPI_BIAS>{});
   };
-  half_epilogue(std::integral_constant<int, NL>{}, 0, n0 + wn * 16 * NL + 4 * NL * g);
-  half_epilogue(std::integral_constant<int, NHI>{}, NL, n0 + 64 * NL + wn * 16 * NHI + 4 * NHI * g);
+  half_epilogue(std::integral_constant<int, NL>{}, 0, nb_lo, braw_lo, graw_lo);
+  half_epilogue(std::integral_constant<int, NHI>{}, NL, nb_hi, braw_hi, graw_hi);
 #ifdef CA_GEMM_STAMP
   if (CA_GEMM_STAMP != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // 2: stores left in flight (the walk as shipped)
   CA_GSTAMP(3);
