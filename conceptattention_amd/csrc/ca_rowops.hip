@@ -114,16 +114,23 @@ __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const XT *__restric
         y[j] = (1.f + sc0[j]) * ((v[c][j] - mean) * rstd) + sh0[j];
         y[4 + j] = (1.f + sc1[j]) * ((v[c][4 + j] - mean) * rstd) + sh1[j];
       }
-      if constexpr (FP8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          v[c][j] = y[j];
-          amax = fmaxf(amax, fabsf(y[j]));
-        }
-      } else {
-        *(uint4 *)((bf16 *)out_ + (size_t)row * ldo + k) =
-            make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] = y[j];
+        if constexpr (FP8) amax = fmaxf(amax, fabsf(y[j]));
       }
+    }
+  }
+  if constexpr (!FP8) {
+    // stores after ALL modulation-vector loads: issued chunk by chunk between the stores, every load waited (vmcnt
+    // retires in order and counts stores) for the acknowledgement of the chunk stored before it
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c) {
+      const int k = c * 512 + lane * 8;
+      if (k < H)
+        *(uint4 *)((bf16 *)out_ + (size_t)row * ldo + k) =
+            make_uint4(ca_pack2(v[c][0], v[c][1]), ca_pack2(v[c][2], v[c][3]), ca_pack2(v[c][4], v[c][5]),
+                       ca_pack2(v[c][6], v[c][7]));
     }
   }
   if constexpr (FP8) {
