@@ -1280,7 +1280,11 @@ int auto_tile(const ca_gemm_problem *p, int n) {
       if (p[i].N % bn) ok = false;
       if (p[i].epilogue == CA_EPI_SPLIT_GELU && p[i].n_split % bn) ok = false;
       if (p[i].epilogue == CA_EPI_QKV_NORM_ROPE && c.tile != CA_TILE_PP_256x256) ok = false;
-      const long t = (long)((p[i].M + 255) / 256) * (p[i].N / bn);
+      long mt = (p[i].M + 255) / 256;
+      const int rem = p[i].M % 256;
+      // a thin last row tile leaves the 256x256 ping-pong walk for the thin-row kernel (a fraction of a round)
+      if (c.tile == CA_TILE_PP_256x256 && rem > 0 && rem <= CA_GEMM_THIN_ROWS && mt > 1) --mt;
+      const long t = mt * (p[i].N / bn);
       tiles += t;
       work += (double)t * p[i].K;
       if (p[i].K > kmax) kmax = p[i].K;
