@@ -318,37 +318,56 @@ __global__ __launch_bounds__(256) void ca_heatmap_logits_kernel(const bf16 *__re
                                                                 float *__restrict__ logits) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *cs = (float *)smem_raw;  // [CC][dim]
-  for (int i = threadIdx.x; i < CC * dim; i += 256) {
-    const int c = i / dim, k = i - c * dim;
-    const int cr = min(c0 + c, C - 1);
-    cs[i] = (float)con[(size_t)cr * ldc + k];
+  for (int c = 0; c < CC; ++c) {  // (dim % 8 == 0, rows 16-byte aligned: four elements per load)
+    const CT *cr = con + (size_t)min(c0 + c, C - 1) * ldc;
+    for (int k = threadIdx.x * 4; k < dim; k += 1024) {
+      f32x4 v;
+      if constexpr (std::is_same<CT, float>::value) {
+        v = *(const f32x4 *)(cr + k);
+      } else {
+        const bf16x4 t = *(const bf16x4 *)(cr + k);
+        v = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+      }
+      *(f32x4 *)(cs + c * dim + k) = v;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  for (int p = blockIdx.x * 4 + wave; p < L; p += gridDim.x * 4) {
-    const bf16 *ir = img + (size_t)p * ldi;
-    float acc[CC];
+  // two patches per wave at a time (their row loads in flight together; one read of the concept vectors from LDS
+  // serves both), each patch with its own accumulation chain in k order
+  for (int p = (blockIdx.x * 4 + wave) * 2; p < L; p += gridDim.x * 8) {
+    const bf16 *ir0 = img + (size_t)p * ldi;
+    const bf16 *ir1 = img + (size_t)min(p + 1, L - 1) * ldi;
+    float acc0[CC], acc1[CC];
 #pragma unroll
-    for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+    for (int c = 0; c < CC; ++c) acc0[c] = acc1[c] = 0.f;
     for (int k = lane * 8; k < dim; k += 512) {
-      const bf16x8 a = *(const bf16x8 *)(ir + k);
+      const bf16x8 a0 = *(const bf16x8 *)(ir0 + k), a1 = *(const bf16x8 *)(ir1 + k);
 #pragma unroll
       for (int c = 0; c < CC; ++c) {
         const f32x4 b0 = *(const f32x4 *)(cs + c * dim + k), b1 = *(const f32x4 *)(cs + c * dim + k + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[c] = fmaf((float)a[j], b0[j], acc[c]);
-          acc[c] = fmaf((float)a[4 + j], b1[j], acc[c]);
+          acc0[c] = fmaf((float)a0[j], b0[j], acc0[c]);
+          acc0[c] = fmaf((float)a0[4 + j], b1[j], acc0[c]);
+          acc1[c] = fmaf((float)a1[j], b0[j], acc1[c]);
+          acc1[c] = fmaf((float)a1[4 + j], b1[j], acc1[c]);
         }
       }
     }
 #pragma unroll
-    for (int c = 0; c < CC; ++c) acc[c] = wave_sum(acc[c]);
+    for (int c = 0; c < CC; ++c) {
+      acc0[c] = wave_sum(acc0[c]);
+      acc1[c] = wave_sum(acc1[c]);
+    }
     if (lane == 0) {
 #pragma unroll
       for (int c = 0; c < CC; ++c)
-        if (c0 + c < C) logits[(size_t)(c0 + c) * L + p] = acc[c];
+        if (c0 + c < C) {
+          logits[(size_t)(c0 + c) * L + p] = acc0[c];
+          if (p + 1 < L) logits[(size_t)(c0 + c) * L + p + 1] = acc1[c];
+        }
     }
   }
 }
@@ -642,11 +661,13 @@ extern "C" int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const vo
                                       int32_t con_is_f32, int32_t L, int32_t C, int32_t dim, float *logits,
                                       ca_stream_t stream) {
   if (!img_vec || !con_vec || !logits || L < 1 || C < 1 || dim < 8 || dim % 8 || dim > 4096 || ldi % 8 ||
-      ldi < dim || ldc < dim || (((uintptr_t)img_vec | (uintptr_t)con_vec) & 15)) {
+      ldi < dim || ldc < dim || ldc % 4 || (((uintptr_t)img_vec | (uintptr_t)con_vec) & 15)) {
     ca_set_error("ca_heatmap_logits_bf16: bad arguments (L=%d C=%d dim=%d ldi=%d ldc=%d)", L, C, dim, ldi, ldc);
     return CA_ERR_ARG;
   }
-  const int grid = (L + 3) / 4 < 2048 ? (L + 3) / 4 : 2048;
+  // 8 patches per workgroup and pass (2 per wave): the 4 * dim floats of concept vectors a workgroup puts into LDS are
+  // then read once per 8 patches, and at most 512 workgroups keep them to 2 per CU's worth of L2 reads
+  const int grid = (L + 7) / 8 < 512 ? (L + 7) / 8 : 512;
   const size_t lds = (size_t)4 * dim * sizeof(float);
   for (int c0 = 0; c0 < C; c0 += 4) {
     if (con_is_f32)

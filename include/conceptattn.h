@@ -220,7 +220,7 @@ int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void *W, const v
  *   acc[c,p]   += weight * softmax_c(logits[:,p])        (weight = 1/(|timesteps|*|layers|), :64-82)
  * fp32 accumulation (the reference does this in bf16; see DESIGN.md "tolerance").
  */
-/* con_vec is bf16 [C,dim] (con_is_f32 = 0) or fp32 [C,dim] (con_is_f32 = 1); ldc in elements. */
+/* con_vec is bf16 [C,dim] (con_is_f32 = 0) or fp32 [C,dim] (con_is_f32 = 1); ldc in elements, a multiple of 4. */
 int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const void *con_vec, int32_t ldc,
                            int32_t con_is_f32, int32_t L, int32_t C, int32_t dim, float *logits,
                            ca_stream_t stream);
