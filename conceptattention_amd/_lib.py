@@ -83,6 +83,8 @@ SIGNATURES = {
     "ca_timestep_embedding_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float,
                                             C.c_void_p]),
     "ca_axpy_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    "ca_silu_split_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p]),
 }
 
 _lib = None

@@ -980,10 +980,19 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
 // into a ring of 4 slots; the DMA of tile t+3 is issued right after the barrier of iteration t (its slot held tile
 // t-1, read before that barrier) and every iteration opens with vmcnt(10) = "all but my two youngest tiles have
 // landed" followed by the barrier that publishes tile t: one barrier per K tile, three tiles in flight.
-constexpr int THIN_M = 32, THIN_N = 128, THIN_STAGE = (THIN_M + THIN_N) * 128, THIN_SLOTS = 4;
-constexpr int THIN_LDS = THIN_SLOTS * THIN_STAGE;
+// MF = 16-row fragments per workgroup: 2 (32 rows: the concept rows of a batch) or 4 (64 rows: longer thin parts and
+// the 2 x items x steps conditioning vectors of the modulation GEMM, so that the weights stream once per 64 rows)
+constexpr int THIN_N = 128, THIN_SLOTS = 4;
+template <int MF>
+struct ThinCfg {
+  static constexpr int M = 16 * MF, STAGE = (M + THIN_N) * 128, LDS = THIN_SLOTS * STAGE;
+  static constexpr int PIECES = (M + THIN_N) / 8 / 4;  // 1 KB pieces per wave and K tile (5 or 6)
+};
 
+template <int MF>
 __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
+  using TC = ThinCfg<MF>;
+  constexpr int THIN_M = TC::M, THIN_STAGE = TC::STAGE, NP = TC::PIECES;
   extern __shared__ __attribute__((aligned(128))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -999,10 +1008,10 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
   const int nk = P.K / 64;
 
   // ---- staging sources: piece q = 5*wave + i covers LDS rows 8q .. 8q+7 (rows 0..31: A, 32..159: W)
-  const char *src[5];
+  const char *src[NP];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int rr = 8 * (5 * wn + i) + (lane >> 3);
+  for (int i = 0; i < NP; ++i) {
+    const int rr = 8 * (NP * wn + i) + (lane >> 3);
     if (rr < THIN_M) {
       const int c = (lane & 7) ^ ((rr >> 1) & 7);
       src[i] = Ab + (size_t)min(m0 + rr, M - 1) * P.lda * 2 + c * 16;
@@ -1016,14 +1025,14 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
   }
   auto stage = [&](int slot, int kt) {
     const int kb = min(kt, nk - 1) * 128;  // (tiles past the end re-stage the last one into a slot nobody reads)
-    char *base = smem + slot * THIN_STAGE + 5 * wn * 1024;
+    char *base = smem + slot * THIN_STAGE + NP * wn * 1024;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) ca_glds16(src[i] + kb, base + i * 1024);
+    for (int i = 0; i < NP; ++i) ca_glds16(src[i] + kb, base + i * 1024);
   };
   const int lane_off = (lane & 15) * 128 + ((((lane >> 4) ^ ((lane & 15) >> 1)) & 7) << 4);
-  f32x4 acc[2][2];
+  f32x4 acc[MF][2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -1031,17 +1040,18 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
   stage(1, 1);
   stage(2, 2);
   for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if constexpr (NP == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // all but my two youngest K tiles
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     stage((t + 3) & 3, t + 3);
     const char *sb = smem + (t & 3) * THIN_STAGE;
-    bf16x8 af[2][2], wf[2][2];
+    bf16x8 af[MF][2], wf[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) af[mi][ks] = *(const bf16x8 *)(sb + ((mi * 16 * 128 + lane_off) ^ (ks * 64)));
+      for (int mi = 0; mi < MF; ++mi) af[mi][ks] = *(const bf16x8 *)(sb + ((mi * 16 * 128 + lane_off) ^ (ks * 64)));
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         wf[j][ks] = *(const bf16x8 *)(sb + (((THIN_M + wn * 32 + j * 16) * 128 + lane_off) ^ (ks * 64)));
@@ -1051,7 +1061,7 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[mi][ks], acc[mi][j], 0, 0, 0);
@@ -1077,10 +1087,10 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
     const int hd = P.n_split / 3;
     const bool is_q = n0 < hd;
     const bf16 *nscale = (const bf16 *)(is_q ? P.norm_q : P.norm_k);
-    float *part = (float *)smem;  // [32 rows][4 column-waves]
-    float x[2][8];
+    float *part = (float *)smem;  // [rows][4 column-waves]
+    float x[MF][8];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MF; ++mi) {
       float sq = 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -1095,9 +1105,9 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
       if (g == 0) part[(16 * mi + l15) * 4 + wn] = sq;
     }
     const int cih = wn * 32 + 8 * g;
-    f32x4 rope0[2], rope1[2];
+    f32x4 rope0[MF], rope1[MF];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MF; ++mi) {
       const float *rp = P.rope + (size_t)min(m0 + 16 * mi + l15, M - 1) * 128 + cih;
       rope0[mi] = *(const f32x4 *)rp;
       rope1[mi] = *(const f32x4 *)(rp + 4);
@@ -1106,7 +1116,7 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
     const int head_col = n0 - (is_q ? 0 : hd);
     const bf16x8 s8 = *(const bf16x8 *)(nscale + cih);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MF; ++mi) {
       const int m = m0 + 16 * mi + l15;
       if (m >= M) continue;
       const f32x4 p4 = *(const f32x4 *)(part + (16 * mi + l15) * 4);
@@ -1142,7 +1152,7 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
     }
   }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MF; ++mi) {
     const int m = m0 + 16 * mi + l15;
     if (m >= M) continue;
     float v[8];
@@ -1179,28 +1189,35 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
   }
 }
 
-int launch_thin(const GemmLaunch &L, hipStream_t stream) {
+template <int MF>
+int launch_thin_mf(const GemmLaunch &L, int groups, hipStream_t stream) {
+  using TC = ThinCfg<MF>;
   static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
   const unsigned long long dev_bit = ca_device_bit();
   if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
-    hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       THIN_LDS);
+    hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_thin_kernel<MF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       TC::LDS);
     if (e != hipSuccess) {
-      ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", THIN_LDS, hipGetErrorString(e));
+      ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", TC::LDS, hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
     attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
-  int groups = 1;  // 32-row groups of the longest thin part
-  for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i)
-    if (L.thin_nt[i]) groups = max(groups, (L.p[i].M - L.thin_row0[i] + THIN_M - 1) / THIN_M);
-  hipLaunchKernelGGL(ca_gemm_thin_kernel, dim3(L.thin_nt[0] + L.thin_nt[1], groups), dim3(256), THIN_LDS, stream, L);
+  hipLaunchKernelGGL(ca_gemm_thin_kernel<MF>, dim3(L.thin_nt[0] + L.thin_nt[1], groups), dim3(256), TC::LDS, stream, L);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ca_set_error("ca_gemm_bf16: thin-row launch failed: %s", hipGetErrorString(e));
     return CA_ERR_LAUNCH;
   }
   return CA_OK;
+}
+
+int launch_thin(const GemmLaunch &L, hipStream_t stream) {
+  int rows = 1;  // rows of the longest thin part
+  for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i)
+    if (L.thin_nt[i]) rows = max(rows, L.p[i].M - L.thin_row0[i]);
+  if (rows <= 32) return launch_thin_mf<2>(L, 1, stream);
+  return launch_thin_mf<4>(L, (rows + 63) / 64, stream);  // 64 rows per workgroup, one grid row per 64
 }
 
 template <int NL, int NHI, bool FP8 = false>

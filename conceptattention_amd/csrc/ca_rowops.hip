@@ -712,6 +712,40 @@ extern "C" int ca_heatmap_norm_accumulate(const float *logits, int32_t C, int32_
   return check_launch("ca_heatmap_norm_accumulate");
 }
 
+namespace {
+__global__ __launch_bounds__(256) void ca_silu_split_kernel(const float *__restrict__ x, int ldx, bf16 *__restrict__ hi,
+                                                            bf16 *__restrict__ lo, int ldo, int rows, int K) {
+  const int per_row = K >> 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * per_row; i += gridDim.x * 256) {
+    const int r = i / per_row, k = (i - r * per_row) << 2;
+    const f32x4 v = *(const f32x4 *)(x + (size_t)r * ldx + k);
+    bf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float s = ca_silu(v[j]);
+      h[j] = (bf16)s;
+      l[j] = (bf16)(s - (float)h[j]);
+    }
+    *(bf16x4 *)(hi + (size_t)r * ldo + k) = h;
+    *(bf16x4 *)(lo + (size_t)r * ldo + k) = l;
+  }
+}
+}  // namespace
+
+extern "C" int ca_silu_split_bf16(const float *x, int32_t ldx, void *hi, void *lo, int32_t ldo, int32_t rows, int32_t K,
+                                  ca_stream_t stream) {
+  if (!x || !hi || !lo || rows < 1 || K < 4 || K % 4 || ldx < K || ldo < K || ldx % 4 || ldo % 4 ||
+      (((uintptr_t)x & 15) | (((uintptr_t)hi | (uintptr_t)lo) & 7))) {
+    ca_set_error("ca_silu_split_bf16: bad arguments (rows=%d K=%d ldx=%d ldo=%d)", rows, K, ldx, ldo);
+    return CA_ERR_ARG;
+  }
+  const long n = (long)rows * (K / 4);
+  const long blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+  hipLaunchKernelGGL(ca_silu_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16 *)hi,
+                     (bf16 *)lo, ldo, rows, K);
+  return check_launch("ca_silu_split_bf16");
+}
+
 extern "C" int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream) {
   if (!x || !y || n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) {
     ca_set_error("ca_axpy_bf16: bad arguments (n=%lld)", (long long)n);

@@ -24,6 +24,8 @@ concept attention reads [concept keys | image keys] as two row segments without 
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional
 
@@ -197,6 +199,9 @@ class HipFluxDiT:
         # Default False = the fp32 oracle's behaviour (t and 1000 t exact); True reproduces the reference's bf16
         # values (pinned by tests/golden/timestep_embedding_bf16.npz).
         self.bf16_timesteps = bool(bf16_timesteps)
+        # adaLN modulations of MANY conditioning vectors (all steps x items, precompute_conditioning) as two bf16 MFMA
+        # GEMMs instead of one weight-streaming GEMV pass per 4 vectors (_modulation_rows); False = GEMV only (A/B)
+        self.modulation_by_gemm = os.environ.get("CA_MODULATION_GEMM", "1") != "0"
         self.set_precision(precision)
 
     # ---- reduced-precision mode (BASELINE.json configs[4]; no counterpart in the reference)
@@ -484,21 +489,31 @@ class HipFluxDiT:
         mod = torch.empty(n, B, 2, W.mod_rows, **f32)
         mod2 = mod.view(2 * B * n, W.mod_rows)
         self._vec_chain(tv, yin, gv, hv, vecs)
-        # 4 vectors per pass: 4 x 3072 fp32 inputs leave room for 3 workgroups per CU in LDS;
-        # with 8 the weight stream drops from 5.3 to 2.2 TB/s (measured, tools/gemv_bench.py)
-        for r0 in range(0, 2 * B * n, 4):
-            r = slice(r0, min(r0 + 4, 2 * B * n))
-            ops.gemv(vecs[r], W.mod_w, W.mod_b, mod2[r], silu_input=True)
+        self._modulation_rows(vecs, mod2)
         self._mod_steps = mod
         return n
+
+    def _modulation_rows(self, vecs, mod2):
+        """mod2[v] = Modulation.lin(silu(vecs[v])) of every block for all vectors v.  As two bf16 MFMA GEMMs over the
+        stacked [sum N, H] weights (silu(vec) split into hi + lo bf16 planes: ~16 mantissa bits; ops.modulation_gemm),
+        which stream the 6.4 GB of weights twice in all; where the shape does not fit that kernel, by weight-streaming
+        GEMV launches of 4 vectors (4 x 3072 fp32 inputs leave room for 3 workgroups per CU in LDS; with 8 the weight
+        stream drops from 5.3 to 2.2 TB/s: tools/gemv_bench.py), i.e. once per 4 vectors."""
+        W = self.weights
+        if self.modulation_by_gemm:  # (for ANY vector count: the per-call and the all-steps path must round alike)
+            if getattr(W, "mod_ones", None) is None:
+                W.mod_ones = torch.ones(W.mod_rows, device=self.device, dtype=torch.float32)
+            if ops.modulation_gemm(vecs, W.mod_w, W.mod_b, mod2, W.mod_ones):
+                return
+        for r0 in range(0, vecs.shape[0], 4):
+            r = slice(r0, min(r0 + 4, vecs.shape[0]))
+            ops.gemv(vecs[r], W.mod_w, W.mod_b, mod2[r], silu_input=True)
 
     def _modulations(self):
         """Every block's adaLN shift/scale/gate from VEC (rows 2j / 2j+1 = vec / concept_vec of item j) by
         weight-streaming launches of at most 4 vectors (Modulation, flux/modules/layers.py:113-126)."""
         mod2 = self.MOD.view(-1, self.weights.mod_rows)
-        for r0 in range(0, mod2.shape[0], 4):
-            r = slice(r0, min(r0 + 4, mod2.shape[0]))
-            ops.gemv(self.VEC[r], self.weights.mod_w, self.weights.mod_b, mod2[r], silu_input=True)
+        self._modulation_rows(self.VEC[:mod2.shape[0]], mod2)
         self._mod_cur = self.MOD
 
     def _double_block(self, i, g, joint_attention_kwargs=None, out=None, return_vectors=False, heatmaps=None):

@@ -281,6 +281,40 @@ def gemv(x, w, bias, out, silu_input=False, accumulate=False) -> None:
                              w.shape[0], w.shape[1], int(silu_input), int(accumulate), _stream()), "ca_gemv_bf16")
 
 
+def silu_split(x, hi, lo) -> None:
+    """hi + lo = silu(x) to ~16 mantissa bits, as two bf16 planes (x fp32 [rows,K]; hi, lo bf16 [rows,K])."""
+    lib = L.load()
+    _chk(x, torch.float32, "x"), _chk(hi, torch.bfloat16, "hi"), _chk(lo, torch.bfloat16, "lo")
+    if x.dim() != 2 or hi.shape != x.shape or lo.shape != x.shape or hi.stride(0) != lo.stride(0):
+        raise ValueError("silu_split: x, hi, lo must be [rows,K] of one shape (hi / lo of one row stride)")
+    L.check(lib.ca_silu_split_bf16(x.data_ptr(), x.stride(0), hi.data_ptr(), lo.data_ptr(), hi.stride(0), x.shape[0],
+                                   x.shape[1], _stream()), "ca_silu_split_bf16")
+
+
+def modulation_gemm(vecs, w, bias, out, ones) -> bool:
+    """out[v,:] = silu(vecs[v,:]) @ w.T + bias for MANY vectors with the weights streamed twice in all (ca_gemv
+    streams them once per 4 vectors): silu(vecs) as two bf16 planes through the thin-row GEMM kernel, the second
+    plane accumulating into the fp32 output (gate = ones).  vecs fp32 [nv,K], w bf16 [N,K], bias bf16 [N], out fp32
+    [nv,N], ones fp32 [N].  Returns False (nothing launched) when the shape does not fit that kernel (N % 256,
+    K % 64, nv > 128): the caller then uses gemv."""
+    nv, K = vecs.shape
+    N = w.shape[0]
+    if N % 256 or K % 64 or nv > 128 or nv < 1 or not w.is_contiguous():
+        return False
+    hi = torch.empty(nv, K, device=vecs.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi)
+    silu_split(vecs, hi, lo)
+    # column chunks of fewer than 2^32 weight bytes (the GEMM's 32-bit operand offsets), multiples of 256 columns
+    n_chunks = -(-N * K * 2 // ((1 << 32) - 1))
+    step = -(-(N // 256) // n_chunks) * 256
+    for c0 in range(0, N, step):
+        c1 = min(c0 + step, N)
+        o = out[:, c0:c1]
+        gemm([Gemm(hi, w[c0:c1], None if bias is None else bias[c0:c1], o, L.EPI_BIAS)], L.TILE_PP_256x256)
+        gemm([Gemm(lo, w[c0:c1], None, o, L.EPI_GATE_RESIDUAL, resid=o, gate=ones[c0:c1])], L.TILE_PP_256x256)
+    return True
+
+
 def heatmap_logits(img_vec, con_vec, logits) -> None:
     """logits[c,p] = <img_vec[p,:], con_vec[c,:]>; img bf16 [L,dim], con bf16|fp32 [C,dim] -> fp32 [C,L]."""
     lib = L.load()

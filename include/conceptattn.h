@@ -246,6 +246,14 @@ int ca_timestep_embedding_f32(const float *t, int32_t nt, float *out, int32_t di
 /* Euler step of denoise(): x = x + a*y  (flux/sampling.py:141), bf16 in/out, fp32 math. */
 int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream);
 
+/* silu(x) of the conditioning vectors (Modulation: lin(silu(vec)), flux/modules/layers.py:113-126) split into two
+ * bf16 planes, hi = bf16(s), lo = bf16(s - hi): hi + lo carries s to ~16 mantissa bits, so that the adaLN modulation
+ * of every block -- [2 * items * steps, H] x [sum N, H]^T, the weights streamed ONCE -- can run as two bf16 MFMA GEMMs
+ * (ca_gemm_bf16, the second one accumulating) instead of one weight pass per 4 vectors (ca_gemv_bf16).
+ * x fp32 [rows, K] (row stride ldx), hi / lo bf16 [rows, K] (row stride ldo), K % 4 == 0. */
+int ca_silu_split_bf16(const float *x, int32_t ldx, void *hi, void *lo, int32_t ldo, int32_t rows, int32_t K,
+                       ca_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

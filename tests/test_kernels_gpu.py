@@ -361,6 +361,33 @@ def test_gemv(nv, K, N):
     assert (out - (ref + x @ w.float().t())).abs().max() < 4e-3
 
 
+@pytest.mark.parametrize("nv", [5, 40, 100])
+def test_modulation_gemm_matches_gemv(nv):
+    """adaLN modulations of many conditioning vectors as two bf16 GEMMs (silu(vec) split into hi + lo planes, thin-row
+    kernel of 64 rows per workgroup, second plane accumulating) against the fp32-input GEMV: the planes carry silu(vec)
+    to ~16 mantissa bits, so the two agree to a few 1e-5 relative of the row's scale; and the result of a vector must
+    not depend on which other vectors share the launch (bit for bit)."""
+    K, N = 256, 1536
+    vecs = torch.randn(nv, K, device=DEV)
+    w, b = rnd(N, K, scale=0.1), rnd(N)
+    ones = torch.ones(N, device=DEV)
+    hi, lo = torch.empty(nv, K, device=DEV, dtype=torch.bfloat16), torch.empty(nv, K, device=DEV, dtype=torch.bfloat16)
+    ops.silu_split(vecs, hi, lo)
+    s = torch.nn.functional.silu(vecs)
+    assert (hi.float() + lo.float() - s).abs().max() <= 2e-5 * s.abs().max()
+    out = torch.empty(nv, N, device=DEV)
+    assert ops.modulation_gemm(vecs, w, b, out, ones)
+    ref = torch.empty(nv, N, device=DEV)
+    for r0 in range(0, nv, 4):
+        ops.gemv(vecs[r0:r0 + 4], w, b, ref[r0:r0 + 4], silu_input=True)
+    assert (out - ref).abs().max() <= 3e-5 * ref.abs().max() + 1e-6
+    close(out, s @ w.float().t() + b.float(), atol=1e-3, rtol=1e-4)
+    alone = torch.empty(3, N, device=DEV)
+    assert ops.modulation_gemm(vecs[1:4].contiguous(), w, b, alone, ones)
+    assert torch.equal(alone, out[1:4])
+    assert not ops.modulation_gemm(vecs, w[:1000], b[:1000], out[:, :1000], ones[:1000])  # N % 256: caller falls back
+
+
 @pytest.mark.parametrize("C", [1, 4, 6])
 def test_heatmap_logits_softmax_accumulate(C):
     Lp, dim = 4096, 3072

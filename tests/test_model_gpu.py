@@ -96,8 +96,8 @@ def test_tiny_stop_after_multimodal_and_fused_heatmaps():
 
 @pytest.mark.parametrize("guidance_embed", [False, True])
 def test_precomputed_conditioning_equals_per_step(guidance_embed):
-    """precompute_conditioning (all steps' modulations in one weight pass) is bit-identical to the
-    per-call path, also for more than 4 steps (two gemv passes)."""
+    """precompute_conditioning (all steps' modulations in one pair of weight passes) is bit-identical to the
+    per-call path: a vector's modulation does not depend on how many vectors share the launch."""
     p, sd, inp = tiny_case(guidance_embed, depth=1, singles=1)
     m = HipFluxDiT(p, DEV)
     m.load_state_dict(sd)
