@@ -746,6 +746,42 @@ extern "C" int ca_silu_split_bf16(const float *x, int32_t ldx, void *hi, void *l
   return check_launch("ca_silu_split_bf16");
 }
 
+namespace {
+__global__ __launch_bounds__(256) void ca_modulation_combine_kernel(const float *__restrict__ pair, int ldp,
+                                                                    const bf16 *__restrict__ bias, float *__restrict__ out,
+                                                                    int ldo, int nv, int N) {
+  const long per_row = N >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv * per_row; i += (long)gridDim.x * 256) {
+    const int v = (int)(i / per_row), n = (int)(i - v * per_row) << 2;
+    const f32x4 h = *(const f32x4 *)(pair + (size_t)v * ldp + n), l = *(const f32x4 *)(pair + (size_t)(nv + v) * ldp + n);
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      const bf16x4 b4 = *(const bf16x4 *)(bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = (float)b4[j];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (h[j] + b[j]) + l[j];
+    *(f32x4 *)(out + (size_t)v * ldo + n) = o;
+  }
+}
+}  // namespace
+
+extern "C" int ca_modulation_combine_f32(const float *pair, int32_t ldp, const void *bias, float *out, int32_t ldo,
+                                         int32_t nv, int32_t N, ca_stream_t stream) {
+  if (!pair || !out || nv < 1 || N < 4 || N % 4 || ldp < N || ldo < N || ldp % 4 || ldo % 4 ||
+      ((((uintptr_t)pair | (uintptr_t)out) & 15) | ((uintptr_t)bias & 7))) {
+    ca_set_error("ca_modulation_combine_f32: bad arguments (nv=%d N=%d ldp=%d ldo=%d)", nv, N, ldp, ldo);
+    return CA_ERR_ARG;
+  }
+  const long n = (long)nv * (N / 4);
+  const long blocks = (n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048;
+  hipLaunchKernelGGL(ca_modulation_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pair, ldp,
+                     (const bf16 *)bias, out, ldo, nv, N);
+  return check_launch("ca_modulation_combine_f32");
+}
+
 extern "C" int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream) {
   if (!x || !y || n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) {
     ca_set_error("ca_axpy_bf16: bad arguments (n=%lld)", (long long)n);

@@ -292,26 +292,37 @@ def silu_split(x, hi, lo) -> None:
 
 
 def modulation_gemm(vecs, w, bias, out, ones) -> bool:
-    """out[v,:] = silu(vecs[v,:]) @ w.T + bias for MANY vectors with the weights streamed twice in all (ca_gemv
-    streams them once per 4 vectors): silu(vecs) as two bf16 planes through the thin-row GEMM kernel, the second
-    plane accumulating into the fp32 output (gate = ones).  vecs fp32 [nv,K], w bf16 [N,K], bias bf16 [N], out fp32
-    [nv,N], ones fp32 [N].  Returns False (nothing launched) when the shape does not fit that kernel (N % 256,
-    K % 64, nv > 128): the caller then uses gemv."""
+    """out[v,:] = silu(vecs[v,:]) @ w.T + bias for any number of vectors through the thin-row GEMM kernel (ca_gemv
+    streams the weights once per 4 vectors): silu(vecs) as two bf16 planes hi + lo.  Up to 32 vectors: ONE weight pass
+    over the stacked rows [hi; lo] (64 rows per workgroup), the two planes' products folded by ca_modulation_combine;
+    more: two passes, the second plane accumulating into the fp32 output (gate = ones).  Both forms round alike
+    ((hi.w + bias) + lo.w), so a vector's result does not depend on the count.  vecs fp32 [nv,K], w bf16 [N,K], bias
+    bf16 [N], out fp32 [nv,N], ones fp32 [N].  Returns False (nothing launched) when the shape does not fit that kernel
+    (N % 256, K % 64, nv > 128): the caller then uses gemv."""
     nv, K = vecs.shape
     N = w.shape[0]
     if N % 256 or K % 64 or nv > 128 or nv < 1 or not w.is_contiguous():
         return False
-    hi = torch.empty(nv, K, device=vecs.device, dtype=torch.bfloat16)
-    lo = torch.empty_like(hi)
+    lib = L.load()
+    planes = torch.empty(2 * nv, K, device=vecs.device, dtype=torch.bfloat16)
+    hi, lo = planes[:nv], planes[nv:]
     silu_split(vecs, hi, lo)
     # column chunks of fewer than 2^32 weight bytes (the GEMM's 32-bit operand offsets), multiples of 256 columns
     n_chunks = -(-N * K * 2 // ((1 << 32) - 1))
     step = -(-(N // 256) // n_chunks) * 256
+    pair = torch.empty(2 * nv, N, device=vecs.device, dtype=torch.float32) if nv <= 32 else None
     for c0 in range(0, N, step):
         c1 = min(c0 + step, N)
+        if pair is not None:
+            gemm([Gemm(planes, w[c0:c1], None, pair[:, c0:c1], L.EPI_BIAS)], L.TILE_PP_256x256)
+            continue
         o = out[:, c0:c1]
         gemm([Gemm(hi, w[c0:c1], None if bias is None else bias[c0:c1], o, L.EPI_BIAS)], L.TILE_PP_256x256)
         gemm([Gemm(lo, w[c0:c1], None, o, L.EPI_GATE_RESIDUAL, resid=o, gate=ones[c0:c1])], L.TILE_PP_256x256)
+    if pair is not None:
+        _chk(out, torch.float32, "out")
+        L.check(lib.ca_modulation_combine_f32(pair.data_ptr(), pair.stride(0), _ptr(bias), out.data_ptr(), out.stride(0),
+                                              nv, N, _stream()), "ca_modulation_combine_f32")
     return True
 
 

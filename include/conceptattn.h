@@ -254,6 +254,13 @@ int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream)
 int ca_silu_split_bf16(const float *x, int32_t ldx, void *hi, void *lo, int32_t ldo, int32_t rows, int32_t K,
                        ca_stream_t stream);
 
+/* The two planes' products of a single-pass modulation GEMM ([hi; lo] stacked as 2*nv rows, no bias) folded into the
+ * modulation: out[v,n] = (pair[v,n] + bias[n]) + pair[nv + v,n] -- the roundings of the two-launch form (first GEMM
+ * with bias, second one accumulating), so both forms give the same bits.  pair fp32 [2*nv, N] (row stride ldp),
+ * bias bf16 [N] or NULL, out fp32 [nv, N] (row stride ldo), N % 4 == 0. */
+int ca_modulation_combine_f32(const float *pair, int32_t ldp, const void *bias, float *out, int32_t ldo, int32_t nv,
+                              int32_t N, ca_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
