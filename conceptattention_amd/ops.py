@@ -298,11 +298,15 @@ def modulation_gemm(vecs, w, bias, out, ones) -> bool:
     more: two passes, the second plane accumulating into the fp32 output (gate = ones).  Both forms round alike
     ((hi.w + bias) + lo.w), so a vector's result does not depend on the count.  vecs fp32 [nv,K], w bf16 [N,K], bias
     bf16 [N], out fp32 [nv,N], ones fp32 [N].  Returns False (nothing launched) when the shape does not fit that kernel
-    (N % 256, K % 64, nv > 128): the caller then uses gemv."""
+    (N % 256, K % 64): the caller then uses gemv."""
     nv, K = vecs.shape
     N = w.shape[0]
-    if N % 256 or K % 64 or nv > 128 or nv < 1 or not w.is_contiguous():
+    if N % 256 or K % 64 or nv < 1 or not w.is_contiguous():
         return False
+    if nv > 128:  # the thin-row kernel takes at most 128 rows per problem: 128 vectors per pair of weight passes
+        for r0 in range(0, nv, 128):
+            modulation_gemm(vecs[r0:r0 + 128], w, bias, out[r0:r0 + 128], ones)
+        return True
     lib = L.load()
     planes = torch.empty(2 * nv, K, device=vecs.device, dtype=torch.bfloat16)
     hi, lo = planes[:nv], planes[nv:]

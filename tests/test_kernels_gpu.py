@@ -361,7 +361,7 @@ def test_gemv(nv, K, N):
     assert (out - (ref + x @ w.float().t())).abs().max() < 4e-3
 
 
-@pytest.mark.parametrize("nv", [5, 40, 100])
+@pytest.mark.parametrize("nv", [5, 40, 100, 300])
 def test_modulation_gemm_matches_gemv(nv):
     """adaLN modulations of many conditioning vectors as two bf16 GEMMs (silu(vec) split into hi + lo planes, thin-row
     kernel of 64 rows per workgroup, second plane accumulating) against the fp32-input GEMV: the planes carry silu(vec)
