@@ -9,11 +9,13 @@ resident in HBM: flux-schnell geometry, 1024x1024 (4096 image tokens), 256 text 
 (BASELINE.json configs[1]; random-init weights, seeded synthetic latents/embeddings).
 N > 1: one process per GPU (torch.distributed.run), a full weight replica per GPU, work items
 round-robin over ranks, ONE RCCL all_gather of the (C,64,64) fp32 maps at the end -- weak scaling.
-Each GPU keeps `--streams` (default 2) independent work items in flight on separate HIP streams that
-share the weights: while one item's kernel runs a partial last wave of workgroups (attention: 408
-workgroups on 256 CUs, several GEMMs likewise) the idle CUs take the other item's workgroups (+5-6 %
-throughput, results bit-identical to one item at a time).  The LAST timed step of every rank runs alone;
-the per-launch HIP-event timing behind `roofline.achieved` is taken there.
+Each GPU sends `--batch` (default 5) independent work items through every forward -- one launch per kernel for all
+of them, so the last round of workgroups of every launch is full (5 x 17 GEMM row tiles, 5 x 408 attention
+workgroups on 256 CUs) -- on `--streams` (default 1) HIP streams; per item the results are bit-identical to a
+single-item call, and rank 0 re-runs the last timed item alone after the timed region to check exactly that
+(`batched_equals_single`).  The LAST group of --batch items of every rank carries the per-launch HIP-event timing
+behind `roofline.achieved`; the groups before it run unperturbed.  `--steps` should be a multiple of `--batch`
+(a ragged last group is run and warmed up too, as a smaller forward).
 Rank 0 prints ONE JSON line.  `value` = heat maps produced by all ranks / wall time (max over ranks).
 """
 from __future__ import annotations
@@ -31,12 +33,15 @@ import torch
 
 # ---- algorithmic FLOPs of the path: GEMM 2MNK, attention 4*Nq*Nk*D*heads,
 #      concept attention counted for the C query rows only, heat map 2*C*L*H per space
-def step_flops(p, L, T, C):
+def step_flops(p, L, T, C, double_blocks_only=False):
+    """One DiT forward; double_blocks_only = the stop_after_multimodal_attentions forward of the encode / sweep paths."""
     H, MLP, NH, D = p.hidden_size, p.mlp_hidden, p.num_heads, p.head_dim
     lin_tok = 2 * H * 3 * H + 2 * H * H + 4 * H * MLP
     dbl = lin_tok * (L + T + C) + 4 * (L + T) ** 2 * D * NH + 4 * C * (C + L) * D * NH + 3 * 2 * H * 6 * H
     sgl = lin_tok * (L + T) + 4 * (L + T) ** 2 * D * NH + 2 * H * 3 * H
     io = 2 * L * p.in_channels * H * 2 + 2 * (T + C) * p.context_in_dim * H
+    if double_blocks_only:
+        return p.depth * dbl + io - 2 * L * p.in_channels * H
     return p.depth * dbl + p.depth_single_blocks * sgl + io
 
 
@@ -95,15 +100,24 @@ def stub_main(args):
     C = args.concepts
     n_timed = world * args.steps
     mine = D.shard_items(n_timed, rank, world)
+    if args.stub_fail_rank is not None and rank == args.stub_fail_rank:
+        raise SystemExit(f"stub: rank {rank} fails on request")
     D.barrier()
     t0 = time.perf_counter()
     local = torch.stack([torch.full((2, C, 4, 4), float(j)) for j in mine])
-    allm = D.gather_heatmaps(local, n_timed, rank, world)
+    if args.workload == "sweep":   # level-sharded table + ONE all_reduce(sum), as the real sweep workload
+        allm = torch.zeros(n_timed, 2, C, 4, 4)
+        allm[mine] = local
+        D.allreduce_sum_(allm)
+    else:                          # generate / encode: item-sharded, ONE all_gather
+        allm = D.gather_heatmaps(local, n_timed, rank, world)
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, "cpu")
     ok = all(bool((allm[j] == float(j)).all()) for j in range(n_timed))
     if rank == 0:
         print(json.dumps({"metric": "STUB (launcher test, no GPU work)", "value": n_timed * C / max(elapsed, 1e-9),
+                          "workload": args.workload,
+                          "collective": "all_reduce" if args.workload == "sweep" else "all_gather",
                           "unit": "stub-items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / args.steps * 1e3, "gathered_in_item_order": ok,
                           "data": "stub"}), flush=True)
@@ -136,7 +150,16 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="flux-schnell")
-    ap.add_argument("--concepts", type=int, default=4)
+    ap.add_argument("--workload", choices=("generate", "encode", "sweep"), default="generate",
+                    help="generate: one generate_image-equivalent call per step (BASELINE.json configs[1]; with --model "
+                         "flux-dev --concepts 8 --diffusion-steps 50: configs[2], one replica per GPU).  encode: one "
+                         "encode_image-equivalent image per step (configs[3]: images sharded over the ranks, one "
+                         "all_gather; default 2 concepts).  sweep: one noise level of the per-layer x noise-level table "
+                         "per step (configs[4]: levels sharded over the ranks, one all_reduce(sum) of the table; add "
+                         "--precision fp8 for the fp8 form)")
+    ap.add_argument("--concepts", type=int, default=None, help="default 4 (2 for --workload encode)")
+    ap.add_argument("--dump-maps", default=None,
+                    help="rank 0 saves the gathered maps [items, 2, ...] to this .npy file (N-rank == 1-rank checks)")
     ap.add_argument("--diffusion-steps", type=int, default=4)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=5,
@@ -155,10 +178,14 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-launch HIP-event timing of the GEMM kernel (roofline.achieved then "
                          "comes from whole-path FLOPs / wall time)")
+    ap.add_argument("--stub-fail-rank", type=int, default=None,
+                    help="TEST ONLY (with --stub-workload): this rank exits non-zero after the rendezvous")
     ap.add_argument("--stub-workload", action="store_true",
                     help="TEST ONLY: replace the GPU work of an item by a constant CPU tensor so that the launcher, "
                          "sharding, gather and JSON plumbing can be exercised without a GPU (gloo); the line says so")
     args = ap.parse_args()
+    if args.concepts is None:
+        args.concepts = 2 if args.workload == "encode" else 4
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
@@ -205,17 +232,39 @@ def main():
     warm_items = [n_timed + rank * n_warm + i for i in range(n_warm)]
     inputs = {j: item_inputs(j) for j in timed_items + warm_items}
 
+    wl = args.workload
+    SWEEP_STEPS = 50   # the schedule the noise levels index (test_segmentations_per_time.py:75-104 sweeps 50 levels)
+    if wl == "generate":
+        gen_kw = dict(layer_indices=layer_indices, num_inference_steps=args.diffusion_steps, guidance=0.0)
+
+        def run_many(js, n_streams, batch):
+            res = pipe.generate_many_on_device([inputs[j] for j in js], n_streams=n_streams, batch=batch, **gen_kw)
+            return [torch.stack((hm[0], cm[0])) for _, hm, cm in res]           # [2, C, side, side] per item
+    elif wl == "encode":
+        enc_kw = dict(layer_indices=layer_indices, num_samples=1, num_steps=4, noise_timestep=2, seed=0)
+
+        def run_many(js, n_streams, batch):
+            res = pipe.encode_many_on_device([inputs[j] for j in js], n_streams=n_streams, batch=batch, **enc_kw)
+            return [torch.stack((ho[0], hc[0])) for ho, hc in res]
+    else:   # sweep: every item is one noise level of the SAME image (item 0's inputs); all 19 layers per level
+        img0 = item_inputs(0)
+
+        def run_many(js, n_streams, batch):
+            out, cross = pipe.layer_noise_sweep_on_device(img0["latent"], img0["txt"], img0["vec"], img0["concepts"],
+                                                          [j % SWEEP_STEPS for j in js], num_steps=SWEEP_STEPS,
+                                                          batch=batch)
+            return [torch.stack((out[k], cross[k])) for k in range(len(js))]   # [2, 19, C, side, side] per level
+
     def run_item(j):
-        i = inputs[j]
-        _, hm, cm = pipe.generate_on_device(i["latent"], i["txt"], i["vec"], i["concepts"],
-                                            layer_indices=layer_indices, num_inference_steps=args.diffusion_steps,
-                                            guidance=0.0)
-        return torch.stack((hm[0], cm[0]))  # [2, C, side, side]
+        return run_many([j], 1, 1)[0]
 
     if warm_items:
-        pipe.generate_many_on_device([inputs[j] for j in warm_items], n_streams=args.streams, batch=args.batch,
-                                     layer_indices=layer_indices, num_inference_steps=args.diffusion_steps,
-                                     guidance=0.0)
+        run_many(warm_items, args.streams, args.batch)
+        # a ragged group (steps not a multiple of --batch) is a forward of another shape: build its activation set
+        # and kernels before the timed region as well (HipFluxDiT keeps the few most recent activation sets)
+        for n_r in sorted({len(timed_items) % args.batch, len(timed_items[:-min(args.batch, len(timed_items))])
+                           % args.batch} - {0}):
+            run_many(warm_items[:n_r], 1, args.batch)
 
     # ---- per-launch timing of the GEMM kernel with HIP events on the launch stream.  Every event pair
     # costs a ~5 us pipeline drain around the launch (616 GEMM launches per call = 2.3 % of a call), so
@@ -248,21 +297,23 @@ def main():
     # the LAST group of --batch items runs with the per-launch HIP-event timing; the groups before it unperturbed
     n_last = min(max(1, args.batch), len(timed_items))
     head, last = timed_items[:-n_last], timed_items[-n_last:]
-    gen_kw = dict(layer_indices=layer_indices, num_inference_steps=args.diffusion_steps, guidance=0.0)
     if head:
-        res = pipe.generate_many_on_device([inputs[j] for j in head], n_streams=args.streams, batch=args.batch,
-                                           **gen_kw)
-        local_maps += [torch.stack((hm[0], cm[0])) for _, hm, cm in res]
+        local_maps += run_many(head, args.streams, args.batch)
     if not args.no_kernel_timing:
         ops.set_gemm_hook(hook)
         ops.set_attn_hook(attn_hook)
-    res = pipe.generate_many_on_device([inputs[j] for j in last], n_streams=1, batch=args.batch, **gen_kw)
-    local_maps += [torch.stack((hm[0], cm[0])) for _, hm, cm in res]
+    local_maps += run_many(last, 1, args.batch)
     ops.set_gemm_hook(None)
     ops.set_attn_hook(None)
     local_maps = torch.stack(local_maps)
-    # the one collective of the job: gather the small fp32 maps of all ranks in item order (RCCL over xGMI)
-    all_maps = D.gather_heatmaps(local_maps, n_timed, rank, world)
+    if wl == "sweep":
+        # level-sharded table: every rank fills the rows of its own levels, ONE all_reduce(sum)
+        all_maps = torch.zeros((n_timed,) + tuple(local_maps.shape[1:]), device=dev)
+        all_maps[timed_items] = local_maps
+        D.allreduce_sum_(all_maps)
+    else:
+        # the one collective of the job: gather the small fp32 maps of all ranks in item order (RCCL over xGMI)
+        all_maps = D.gather_heatmaps(local_maps, n_timed, rank, world)
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
@@ -306,11 +357,43 @@ def main():
                          "per work item", "us": med,
                  "tflop": dbl_flops / 1e12, "achieved_tflops": dbl_flops / med / 1e6,
                  "mfma_frac": dbl_flops / med / 1e6 / MFMA_BF16_PEAK_TFLOPS}
-    maps_ok = bool(torch.isfinite(all_maps).all().item()) and abs(all_maps[:, 0].sum(1).mean().item() - 1.0) < 1e-3
+    if not bool(torch.isfinite(all_maps).all().item()):
+        raise SystemExit("bench: non-finite heat maps")
+    # ---- the batched forward against the reference's unit of work (ONE item per call,
+    # concept_attention_pipeline.py:115-202): the last timed item of rank 0 again, alone, outside the timed region;
+    # its maps must equal the ones the batched group produced bit for bit
+    batched_equals_single = None
+    if rank == 0 and timed_items:
+        solo = run_item(timed_items[-1])
+        torch.cuda.synchronize()
+        batched_equals_single = bool(torch.equal(solo, local_maps[-1]))
 
     if rank == 0:
-        flops_call = args.diffusion_steps * step_flops(p, Lp, T, C) + \
-            len(layer_indices) * args.diffusion_steps * 2 * (2 * C * Lp * p.hidden_size)
+        if wl == "generate":
+            flops_call = args.diffusion_steps * step_flops(p, Lp, T, C) + \
+                len(layer_indices) * args.diffusion_steps * 2 * (2 * C * Lp * p.hidden_size)
+            maps_per_item = C
+            metric = f"concept-heatmaps/sec ({args.size}x{args.size}, {C} concepts, {args.diffusion_steps} steps)"
+            workload = (f"{args.model} {args.precision} {args.size}x{args.size}, {C} concepts, "
+                        f"{args.diffusion_steps} diffusion steps, {T} text tokens "
+                        "(generate_image-equivalent call; random-init weights, synthetic latents/embeddings)")
+        elif wl == "encode":
+            flops_call = step_flops(p, Lp, T, C, True) + len(layer_indices) * 2 * (2 * C * Lp * p.hidden_size)
+            maps_per_item = C
+            metric = (f"concept-heatmaps/sec (encode_image path: {args.size}x{args.size}, {C} concepts, one forward of "
+                      "the 19 double blocks per image)")
+            workload = (f"{args.model} {args.precision} {args.size}x{args.size}, {C} concepts, {T} text tokens, "
+                        "encode_image-equivalent call per image (add_noise_to_image at schedule[2] of 4 + ONE "
+                        "stop_after_multimodal_attentions forward; random-init weights, synthetic latents/embeddings); "
+                        "images sharded over the ranks, one all_gather")
+        else:
+            flops_call = step_flops(p, Lp, T, C, True) + p.depth * 2 * (2 * C * Lp * p.hidden_size)
+            maps_per_item = C * p.depth
+            metric = (f"concept-heatmaps/sec (per-layer x noise-level sweep: {args.size}x{args.size}, {C} concepts x "
+                      f"{p.depth} double blocks per noise level)")
+            workload = (f"{args.model} {args.precision} {args.size}x{args.size}, {C} concepts, {T} text tokens, one noise "
+                        f"level of {SWEEP_STEPS} per step (one stop_after_multimodal_attentions forward, maps of all "
+                        f"{p.depth} double blocks in both spaces); levels sharded over the ranks, one all_reduce(sum)")
         path_tflops = flops_call * calls / elapsed / 1e12 / world  # per GPU
         fp8 = args.precision == "fp8"
         roof = {"bound": "mfma", "peak": MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -374,30 +457,35 @@ def main():
                             "peak (attention and the small kernels stay bf16); frac is the e4m3 GEMM kernel "
                             "against the 5 PFLOP/s fp8 peak")
         res = {
-            "metric": f"concept-heatmaps/sec ({args.size}x{args.size}, {C} concepts, {args.diffusion_steps} steps)",
-            "value": calls * C / elapsed,
+            "metric": metric,
+            "value": calls * maps_per_item / elapsed,
             "unit": "concept-heatmaps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8(e4m3 projections)+bf16" if fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.model} {args.precision} {args.size}x{args.size}, {C} concepts, "
-                                   f"{args.diffusion_steps} diffusion steps, {T} text tokens "
-                                   "(generate_image-equivalent call; random-init weights, synthetic latents/embeddings)",
-                       "calls_per_step_per_gpu": 1, "heatmap_layers": layer_indices,
+            "config": {"workload": workload,
+                       "calls_per_step_per_gpu": 1,
+                       "heatmap_layers": layer_indices if wl != "sweep" else list(range(p.depth)),
                        "tflop_per_call": flops_call / 1e12, "parallelism": f"replica x{world} (work items round-robin)",
                        "items_per_forward": args.batch, "streams_per_gpu": args.streams,
                        "residual_stream": args.residual,
                        **({"fp8_scope": "qkv/proj/mlp/linear1/linear2 of all blocks except double blocks "
                                         f"{layer_indices} (the heat-map layers stay bf16)"} if fp8 else {})},
             "calls_per_s": calls / elapsed,
-            "outputs_finite_and_normalised": maps_ok,
+            "batched_equals_single": batched_equals_single,
             "roofline": roof,
             "roofline_attention": roof_attn,
             "concept_attention_block": block,
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(p, Lp, T, C, args.diffusion_steps, p.depth, p.depth_single_blocks)
+            res["cpu_baseline"] = cpu_baseline(p, Lp, T, C, args.diffusion_steps if wl == "generate" else 1, p.depth,
+                                               p.depth_single_blocks if wl == "generate" else 0)
+            if wl == "sweep":   # per level the oracle produces C x depth maps too
+                res["cpu_baseline"]["value"] *= p.depth
+        if args.dump_maps:
+            import numpy as np
+            np.save(args.dump_maps, all_maps.float().cpu().numpy())
         print(json.dumps(res), flush=True)
     D.barrier()
     if torch.distributed.is_initialized():

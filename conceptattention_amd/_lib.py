@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconceptattn.so")
 
-CA_VERSION = 110
+CA_VERSION = 120
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU, EPI_QKV_NORM_ROPE = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_256x256, TILE_256x192, TILE_256x128, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_PP_256x256, TILE_PP_256x128, TILE_PP_256x192 = 5, 6, 7
@@ -20,6 +20,7 @@ NORMS = {"softmax": NORM_SOFTMAX, "sparsemax": NORM_SPARSEMAX, "entmax15": NORM_
 MAX_SEGMENTS = 16
 GEMM_MAX_PROBLEMS = 2
 ATTN_MAX_PROBLEMS = 16
+ATTN_Q_PRESCALED = 0.0   # ca_attn_fwd_bf16(scale=...): the q rows already carry softmax_scale * log2(e)
 
 
 class GemmProblem(C.Structure):
@@ -31,7 +32,8 @@ class GemmProblem(C.Structure):
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("ld2", C.c_int32), ("n_split", C.c_int32), ("gate_rows", C.c_int32),
                 ("epilogue", C.c_int32), ("ldp", C.c_int32), ("out_f32", C.c_int32), ("gate_stride", C.c_int32),
-                ("gate_item_rows", C.c_int32), ("gate2_item_rows", C.c_int32)]
+                ("gate_item_rows", C.c_int32), ("gate2_item_rows", C.c_int32),
+                ("qpre_f32", C.c_int32), ("q_out_scale", C.c_float)]
 
 
 class AttnProblem(C.Structure):

@@ -52,7 +52,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16 &s, int base) {
   return r;
 }
 
-template <int NW>  // waves per workgroup: 8 (256 query rows, 1 workgroup per CU) or 4 (128 rows, 2 per CU)
+// NW = waves per workgroup: 8 (256 query rows, 1 workgroup per CU) or 4 (128 rows, 2 per CU).
+// PRE = the q rows already carry softmax_scale * log2(e) (CA_ATTN_Q_PRESCALED): a tile's scores then leave the
+// K Q^T chain as s - reference (the chain's first MFMA takes a register block holding -reference as its C operand),
+// so a probability is ONE v_exp_f32 per score: no multiply, no subtract.
+template <int NW, bool PRE = false>
 __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int tid = threadIdx.x;
@@ -157,7 +161,10 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
-  const float sl2 = L.scale_log2;
+  const float sl2 = PRE ? 1.0f : L.scale_log2;
+  f32x16 negm;   // PRE: every register = -m_run of this lane's query row (rewritten only when the reference moves)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
   const int nt = (nkeys + KV_TILE - 1) / KV_TILE;
   stage_tile(0, 0);
@@ -186,30 +193,34 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
     // way: S recomputed, reference raised to the new maximum, O^T and l rescaled.  Nothing of the tile has been
     // added to l or O^T at that point, so everything at the old reference is rescaled exactly once.
     f32x16 s[2];
-    float rs;
-    bool with_max = FIRST;
-#pragma nounroll
-    for (;;) {
+    float rs = 0.f;
+    // K Q^T of the tile; CINIT = the accumulators start from `negm` (PRE fast pass) instead of zero
+    auto qk = [&](auto cinit_tag) {
+      constexpr bool CINIT = decltype(cinit_tag)::value;
       asm volatile("" ::: "memory");  // the K fragments are re-read per pass (hoisted, they would pin 64 VGPRs)
-      {
-        // K fragments PF MFMAs ahead of their use: an LDS read takes 2-4 MFMA slots to come back, and left to itself
-        // hipcc sinks every read to its MFMA (one fragment register, lgkmcnt(0) before each MFMA) to save registers.
-        // sched_barrier(0) pins the order; the wait counts are still the compiler's.
-        constexpr int PF = CA_ATTN_KPF;
-        bf16x8 kq[PF];
+      // K fragments PF MFMAs ahead of their use: an LDS read takes 2-4 MFMA slots to come back, and left to itself
+      // hipcc sinks every read to its MFMA (one fragment register, lgkmcnt(0) before each MFMA) to save registers.
+      // sched_barrier(0) pins the order; the wait counts are still the compiler's.
+      constexpr int PF = CA_ATTN_KPF;
+      bf16x8 kq[PF];
 #pragma unroll
-        for (int i = 0; i < PF; ++i) kq[i] = *(const bf16x8 *)(kbuf + (i >> 3) * 8192 + (k_lane ^ ((i & 7) << 5)));
+      for (int i = 0; i < PF; ++i) kq[i] = *(const bf16x8 *)(kbuf + (i >> 3) * 8192 + (k_lane ^ ((i & 7) << 5)));
+      if constexpr (CINIT) {
+        asm volatile("" : "+v"(negm));  // opaque: hipcc must keep the block in registers, not re-splat it per tile
+        s[0] = negm;
+        s[1] = negm;
+      } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[0][r] = s[1][r] = 0.f;
-        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          s[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kq[i % PF], qf[i & 7], s[i >> 3], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) {
+        s[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kq[i % PF], qf[i & 7], s[i >> 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + PF < 16) {
+          kq[i % PF] = *(const bf16x8 *)(kbuf + ((i + PF) >> 3) * 8192 + (k_lane ^ (((i + PF) & 7) << 5)));
           __builtin_amdgcn_sched_barrier(0);
-          if (i + PF < 16) {
-            kq[i % PF] = *(const bf16x8 *)(kbuf + ((i + PF) >> 3) * 8192 + (k_lane ^ (((i + PF) & 7) << 5)));
-            __builtin_amdgcn_sched_barrier(0);
-          }
         }
       }
       if constexpr (MASKED) {  // key = 64*t + 32*kb + (r&3) + 8*(r>>2) + 4*h
@@ -221,35 +232,61 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
             if (key >= nkeys) s[kb][r] = -INFINITY;
           }
       }
-      if (with_max) {  // wave-uniform
-        // this lane: query row ql, 32 of the tile's 64 keys; lane^32 has the rest
-        float mx = s[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-      }
+    };
+    bool done = false;
+    if constexpr (PRE && !FIRST) {
+      // fast pass: scores arrive as s - reference, a probability is one v_exp_f32
+      qk(std::true_type{});
       rs = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_run));
+          const float p = __builtin_amdgcn_exp2f(s[kb][r]);
           s[kb][r] = p;
           rs += p;
         }
-      // (a row whose keys are all masked so far has m_run = -1e30 and rs = 0: not > the limit; inf compares true)
-      if (with_max || __builtin_amdgcn_ballot_w64(!(rs <= REDO_LIMIT)) == 0) break;
-      with_max = true;
+      done = __builtin_amdgcn_ballot_w64(!(rs <= REDO_LIMIT)) == 0;
+    }
+    if (!done) {
+      bool with_max = FIRST || PRE;   // (PRE: this block is the first tile or a redo, both with the maximum)
+#pragma nounroll
+      for (;;) {
+        qk(std::false_type{});
+        if (with_max) {  // wave-uniform
+          // this lane: query row ql, 32 of the tile's 64 keys; lane^32 has the rest
+          float mx = s[0][0];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl2;
+          const float m_new = fmaxf(m_run, mx);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+          l_run *= alpha;
+#pragma unroll
+          for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+          if constexpr (PRE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+          }
+        }
+        rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(PRE ? s[kb][r] - m_run : fmaf(s[kb][r], sl2, -m_run));
+            s[kb][r] = p;
+            rs += p;
+          }
+        // (a row whose keys are all masked so far has m_run = -1e30 and rs = 0: not > the limit; inf compares true)
+        if (with_max || __builtin_amdgcn_ballot_w64(!(rs <= REDO_LIMIT)) == 0) break;
+        with_max = true;
+      }
     }
     l_run += rs;
     // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; P^T fragments straight from the S^T registers
@@ -347,10 +384,12 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 
 extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
                                 float scale, ca_stream_t stream) {
-  if (!problems || n_problems < 1 || n_problems > CA_ATTN_MAX_PROBLEMS || num_heads < 1) {
-    ca_set_error("ca_attn_fwd_bf16: n_problems=%d (max %d) num_heads=%d", n_problems, CA_ATTN_MAX_PROBLEMS, num_heads);
+  if (!problems || n_problems < 1 || n_problems > CA_ATTN_MAX_PROBLEMS || num_heads < 1 || !(scale >= 0.0f)) {
+    ca_set_error("ca_attn_fwd_bf16: n_problems=%d (max %d) num_heads=%d scale=%g", n_problems, CA_ATTN_MAX_PROBLEMS,
+                 num_heads, (double)scale);
     return CA_ERR_ARG;
   }
+  const bool pre = scale == CA_ATTN_Q_PRESCALED;
   // Default: 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: ~250 us for
   // 4352x4352x24 heads on MI355X.  A/B aid (same numerics): CA_ATTN_WAVES=4 = 128-row workgroups.
   static const int nw = (getenv("CA_ATTN_WAVES") && atoi(getenv("CA_ATTN_WAVES")) == 4) ? 4 : 8;
@@ -402,20 +441,24 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
   const unsigned long long dev_bit = ca_device_bit();
   if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
-    hipError_t e = hipFuncSetAttribute((const void *)ca_attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       ATTN_LDS);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void *)ca_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
+    hipError_t e = hipSuccess;
+    for (const void *fn : {(const void *)ca_attn_kernel<8>, (const void *)ca_attn_kernel<4>,
+                           (const void *)ca_attn_kernel<8, true>, (const void *)ca_attn_kernel<4, true>})
+      if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
     if (e != hipSuccess) {
       ca_set_error("ca_attn_fwd_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
     attr_done.fetch_or(dev_bit, std::memory_order_release);  // idempotent: a race only repeats the call
   }
-  if (nw == 8)
-    hipLaunchKernelGGL(ca_attn_kernel<8>, dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
+  if (nw == 8 && pre)
+    hipLaunchKernelGGL((ca_attn_kernel<8, true>), dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
+  else if (nw == 8)
+    hipLaunchKernelGGL((ca_attn_kernel<8, false>), dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
+  else if (pre)
+    hipLaunchKernelGGL((ca_attn_kernel<4, true>), dim3(total), dim3(256), ATTN_LDS, (hipStream_t)stream, L);
   else
-    hipLaunchKernelGGL(ca_attn_kernel<4>, dim3(total), dim3(256), ATTN_LDS, (hipStream_t)stream, L);
+    hipLaunchKernelGGL((ca_attn_kernel<4, false>), dim3(total), dim3(256), ATTN_LDS, (hipStream_t)stream, L);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ca_set_error("ca_attn_fwd_bf16: launch failed: %s", hipGetErrorString(e));

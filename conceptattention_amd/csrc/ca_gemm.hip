@@ -729,6 +729,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
       // waited for the acknowledgement of the previous fragment's stores: vmcnt retires in order and counts stores.
       // Stamps of wave 0, per head of 8 fragments: 7500 -> 3700 cycles.)
       const int cih = wn * 32 + 8 * g;             // column inside the head
+      const float qos = P.q_out_scale == 0.0f ? 1.0f : P.q_out_scale;
       f32x4 rope0[8], rope1[8];
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
@@ -759,9 +760,16 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           float y[8];
 #pragma unroll
           for (int t = 0; t < 8; ++t) y[t] = x[mi][hn][t] * rrms * (float)s8[t];
-          if (is_q && P.q_prerope)
-            *(uint4 *)((bf16 *)P.q_prerope + (size_t)m * P.ldp + head_col + cih) =
-                make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+          if (is_q && P.q_prerope) {
+            if (P.qpre_f32) {
+              float *qp = (float *)P.q_prerope + (size_t)m * P.ldp + head_col + cih;
+              *(f32x4 *)qp = f32x4{y[0], y[1], y[2], y[3]};
+              *(f32x4 *)(qp + 4) = f32x4{y[4], y[5], y[6], y[7]};
+            } else {
+              *(uint4 *)((bf16 *)P.q_prerope + (size_t)m * P.ldp + head_col + cih) =
+                  make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+            }
+          }
           const f32x4 r0 = rope0[mi], r1 = rope1[mi];
           const float cs[4] = {r0[0], r0[2], r1[0], r1[2]}, sn[4] = {r0[1], r0[3], r1[1], r1[3]};
           float z[8];
@@ -769,6 +777,10 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           for (int i = 0; i < 4; ++i) {
             z[2 * i] = __builtin_fmaf(cs[i], y[2 * i], -(sn[i] * y[2 * i + 1]));
             z[2 * i + 1] = __builtin_fmaf(sn[i], y[2 * i], cs[i] * y[2 * i + 1]);
+          }
+          if (is_q && qos != 1.0f) {  // (uniform branch; explicit multiply: the thin-row kernel must round alike)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = z[i] * qos;
           }
           *(uint4 *)(outb + ((size_t)m * ldo + n0 + hn * 128 + cih) * 2) =
               make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
@@ -1105,6 +1117,7 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
       if (g == 0) part[(16 * mi + l15) * 4 + wn] = sq;
     }
     const int cih = wn * 32 + 8 * g;
+    const float qos = P.q_out_scale == 0.0f ? 1.0f : P.q_out_scale;
     f32x4 rope0[MF], rope1[MF];
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) {
@@ -1124,9 +1137,16 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
       float y[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) y[t] = x[mi][t] * rrms * (float)s8[t];
-      if (is_q && P.q_prerope)
-        *(uint4 *)((bf16 *)P.q_prerope + (size_t)m * P.ldp + head_col + cih) =
-            make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+      if (is_q && P.q_prerope) {
+        if (P.qpre_f32) {
+          float *qp = (float *)P.q_prerope + (size_t)m * P.ldp + head_col + cih;
+          *(f32x4 *)qp = f32x4{y[0], y[1], y[2], y[3]};
+          *(f32x4 *)(qp + 4) = f32x4{y[4], y[5], y[6], y[7]};
+        } else {
+          *(uint4 *)((bf16 *)P.q_prerope + (size_t)m * P.ldp + head_col + cih) =
+              make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+        }
+      }
       const f32x4 r0 = rope0[mi], r1 = rope1[mi];
       const float cs[4] = {r0[0], r0[2], r1[0], r1[2]}, sn[4] = {r0[1], r0[3], r1[1], r1[3]};
       float z[8];
@@ -1134,6 +1154,10 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
       for (int i = 0; i < 4; ++i) {
         z[2 * i] = __builtin_fmaf(cs[i], y[2 * i], -(sn[i] * y[2 * i + 1]));
         z[2 * i + 1] = __builtin_fmaf(sn[i], y[2 * i], cs[i] * y[2 * i + 1]);
+      }
+      if (is_q && qos != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = z[i] * qos;
       }
       *(uint4 *)(outb + ((size_t)m * ldo + n0 + cih) * 2) =
           make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
@@ -1292,15 +1316,19 @@ int auto_tile(const ca_gemm_problem *p, int n) {
     bool ok = true;
     double work = 0;  // tile-rounds weighted by K (a workgroup's time is proportional to its K loop)
     long tiles = 0;
-    int kmax = 0;
+    int kmax = 0, thin_k = 0;
     for (int i = 0; i < n; ++i) {
       if (p[i].N % bn) ok = false;
       if (p[i].epilogue == CA_EPI_SPLIT_GELU && p[i].n_split % bn) ok = false;
       if (p[i].epilogue == CA_EPI_QKV_NORM_ROPE && c.tile != CA_TILE_PP_256x256) ok = false;
       long mt = (p[i].M + 255) / 256;
       const int rem = p[i].M % 256;
-      // a thin last row tile leaves the 256x256 ping-pong walk for the thin-row kernel (a fraction of a round)
-      if (c.tile == CA_TILE_PP_256x256 && rem > 0 && rem <= CA_GEMM_THIN_ROWS && mt > 1) --mt;
+      // a thin last row tile leaves the 256x256 ping-pong walk for the thin-row kernel (a fraction of a round); the
+      // same predicate as gemm_impl's `own`, M <= 128 (no ping-pong tile at all) included
+      if (c.tile == CA_TILE_PP_256x256 && rem > 0 && rem <= CA_GEMM_THIN_ROWS) {
+        --mt;
+        if (p[i].K > thin_k) thin_k = p[i].K;
+      }
       const long t = mt * (p[i].N / bn);
       tiles += t;
       work += (double)t * p[i].K;
@@ -1309,8 +1337,9 @@ int auto_tile(const ca_gemm_problem *p, int n) {
     if (!ok) continue;
     // makespan estimate: at least one longest tile, at least the K-weighted work spread over 256 CUs
     double rounds = work / kmax / 256.0;
-    rounds = rounds <= 1.0 ? 1.0 : (double)(long)(rounds + 0.999);
-    const double cost = rounds * c.round_us * kmax;
+    rounds = work == 0 ? 0.0 : rounds <= 1.0 ? 1.0 : (double)(long)(rounds + 0.999);
+    // the thin-row launch behind the main one: measured 0.3 of a 256x256 round at its K (profiles/r02_remainder_probe.txt)
+    const double cost = rounds * c.round_us * kmax + 0.3 * c.round_us * thin_k;
     if (cost < best_cost) {
       best_cost = cost;
       best = c.tile;
@@ -1412,7 +1441,7 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
       case CA_EPI_QKV_NORM_ROPE:
         if (tile != CA_TILE_PP_256x256 || p.n_split <= 0 || p.n_split % 768 || p.n_split > p.N || !p.norm_q ||
             !p.norm_k || !p.rope || (p.n_split < p.N && (!p.out2 || p.ld2 % 8 || p.ld2 < p.N - p.n_split)) ||
-            p.ldc < p.n_split || (p.q_prerope && (p.ldp % 8 || p.ldp < p.n_split / 3)) ||
+            p.ldc < p.n_split || (p.q_prerope && (p.ldp % (p.qpre_f32 ? 4 : 8) || p.ldp < p.n_split / 3)) ||
             (((uintptr_t)p.norm_q | (uintptr_t)p.norm_k | (uintptr_t)p.rope | (uintptr_t)p.q_prerope |
               (uintptr_t)p.out2) & 15)) {
           ca_set_error("%s[%d]: QKV_NORM_ROPE needs the 256x256 ping-pong tile, n_split = 3*heads*128 <= N, "

@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256) void ca_gemv_kernel(const float *__restrict__ 
 // ------------------------------------------------------------------------------------------
 // logits[c,p] = <img_vec[p,:], con_vec[c,:]> for CC concepts per pass; one wave per patch.
 // The concept vectors sit in LDS as fp32 (they are either bf16 or already fp32 in HBM).
-template <int CC, typename CT>
-__global__ __launch_bounds__(256) void ca_heatmap_logits_kernel(const bf16 *__restrict__ img, int ldi,
+template <int CC, typename CT, typename IT = bf16>
+__global__ __launch_bounds__(256) void ca_heatmap_logits_kernel(const IT *__restrict__ img, int ldi,
                                                                 const CT *__restrict__ con, int ldc, int L,
                                                                 int C, int c0, int dim,
                                                                 float *__restrict__ logits) {
@@ -337,22 +337,32 @@ __global__ __launch_bounds__(256) void ca_heatmap_logits_kernel(const bf16 *__re
   // two patches per wave at a time (their row loads in flight together; one read of the concept vectors from LDS
   // serves both), each patch with its own accumulation chain in k order
   for (int p = (blockIdx.x * 4 + wave) * 2; p < L; p += gridDim.x * 8) {
-    const bf16 *ir0 = img + (size_t)p * ldi;
-    const bf16 *ir1 = img + (size_t)min(p + 1, L - 1) * ldi;
+    const IT *ir0 = img + (size_t)p * ldi;
+    const IT *ir1 = img + (size_t)min(p + 1, L - 1) * ldi;
     float acc0[CC], acc1[CC];
 #pragma unroll
     for (int c = 0; c < CC; ++c) acc0[c] = acc1[c] = 0.f;
     for (int k = lane * 8; k < dim; k += 512) {
-      const bf16x8 a0 = *(const bf16x8 *)(ir0 + k), a1 = *(const bf16x8 *)(ir1 + k);
+      float a0[8], a1[8];   // the same k order per patch for bf16 and fp32 image vectors
+      if constexpr (std::is_same<IT, float>::value) {
+        const f32x4 u0 = *(const f32x4 *)(ir0 + k), u1 = *(const f32x4 *)(ir0 + k + 4);
+        const f32x4 w0 = *(const f32x4 *)(ir1 + k), w1 = *(const f32x4 *)(ir1 + k + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] = u0[j]; a0[4 + j] = u1[j]; a1[j] = w0[j]; a1[4 + j] = w1[j]; }
+      } else {
+        const bf16x8 u = *(const bf16x8 *)(ir0 + k), w = *(const bf16x8 *)(ir1 + k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a0[j] = (float)u[j]; a1[j] = (float)w[j]; }
+      }
 #pragma unroll
       for (int c = 0; c < CC; ++c) {
         const f32x4 b0 = *(const f32x4 *)(cs + c * dim + k), b1 = *(const f32x4 *)(cs + c * dim + k + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc0[c] = fmaf((float)a0[j], b0[j], acc0[c]);
-          acc0[c] = fmaf((float)a0[4 + j], b1[j], acc0[c]);
-          acc1[c] = fmaf((float)a1[j], b0[j], acc1[c]);
-          acc1[c] = fmaf((float)a1[4 + j], b1[j], acc1[c]);
+          acc0[c] = fmaf(a0[j], b0[j], acc0[c]);
+          acc0[c] = fmaf(a0[4 + j], b1[j], acc0[c]);
+          acc1[c] = fmaf(a1[j], b0[j], acc1[c]);
+          acc1[c] = fmaf(a1[4 + j], b1[j], acc1[c]);
         }
       }
     }
@@ -660,8 +670,10 @@ extern "C" int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void 
 extern "C" int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const void *con_vec, int32_t ldc,
                                       int32_t con_is_f32, int32_t L, int32_t C, int32_t dim, float *logits,
                                       ca_stream_t stream) {
+  const bool con32 = con_is_f32 & 1, img32 = con_is_f32 & 2;   // bit 0: concept vectors fp32, bit 1: image vectors fp32
   if (!img_vec || !con_vec || !logits || L < 1 || C < 1 || dim < 8 || dim % 8 || dim > 4096 || ldi % 8 ||
-      ldi < dim || ldc < dim || ldc % 4 || (((uintptr_t)img_vec | (uintptr_t)con_vec) & 15)) {
+      ldi < dim || ldc < dim || ldc % 4 || (((uintptr_t)img_vec | (uintptr_t)con_vec) & 15) || (con_is_f32 & ~3) ||
+      (img32 && !con32)) {
     ca_set_error("ca_heatmap_logits_bf16: bad arguments (L=%d C=%d dim=%d ldi=%d ldc=%d)", L, C, dim, ldi, ldc);
     return CA_ERR_ARG;
   }
@@ -670,7 +682,10 @@ extern "C" int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const vo
   const int grid = (L + 7) / 8 < 512 ? (L + 7) / 8 : 512;
   const size_t lds = (size_t)4 * dim * sizeof(float);
   for (int c0 = 0; c0 < C; c0 += 4) {
-    if (con_is_f32)
+    if (img32)
+      hipLaunchKernelGGL((ca_heatmap_logits_kernel<4, float, float>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
+                         (const float *)img_vec, ldi, (const float *)con_vec, ldc, L, C, c0, dim, logits);
+    else if (con32)
       hipLaunchKernelGGL((ca_heatmap_logits_kernel<4, float>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
                          (const bf16 *)img_vec, ldi, (const float *)con_vec, ldc, L, C, c0, dim, logits);
     else

@@ -24,6 +24,7 @@ concept attention reads [concept keys | image keys] as two row segments without 
 """
 from __future__ import annotations
 
+import math
 import os
 
 from dataclasses import dataclass
@@ -181,6 +182,7 @@ class HipFluxDiT:
         L.load()
         self.weights = weights if weights is not None else FluxWeights(params, self.device)
         self._ws_key = None
+        self._ws_cache = {}
         self._rope_key = None
         self._mod_cur = None
         self._mod_steps = None
@@ -202,6 +204,10 @@ class HipFluxDiT:
         # adaLN modulations of MANY conditioning vectors (all steps x items, precompute_conditioning) as two bf16 MFMA
         # GEMMs instead of one weight-streaming GEMV pass per 4 vectors (_modulation_rows); False = GEMV only (A/B)
         self.modulation_by_gemm = os.environ.get("CA_MODULATION_GEMM", "1") != "0"
+        # softmax_scale * log2(e) folded into q by the qkv epilogue (in fp32, before q's one rounding to bf16), so the
+        # attention kernel's probability is a bare exp2 (include/conceptattn.h CA_ATTN_Q_PRESCALED); "0" = the kernel
+        # multiplies every score instead (A/B aid)
+        self.prescale_q = os.environ.get("CA_ATTN_PRESCALE", "1") != "0"
         self.set_precision(precision)
 
     # ---- reduced-precision mode (BASELINE.json configs[4]; no counterpart in the reference)
@@ -273,37 +279,54 @@ class HipFluxDiT:
         key = (L_img, T, C, B, self.precision, self.residual_dtype)
         if self._ws_key == key:
             return
+        # A few activation sets stay cached (LRU): callers that alternate shapes -- a ragged last group of a batched
+        # run, B = 1 calls between B = 5 groups -- would otherwise free and re-zero gigabytes inside their loop.
+        cached = self._ws_cache.pop(key, None)
+        if cached is None:
+            cached = self._alloc_workspace(L_img, T, C, B)
+            while len(self._ws_cache) >= self.WS_CACHE_ENTRIES:
+                self._ws_cache.pop(next(iter(self._ws_cache)))
+        self._ws_cache[key] = cached
+        self.__dict__.update(cached)
+        self._ws_key = key
+        self._rope_key = None
+
+    WS_CACHE_ENTRIES = 3
+
+    def _alloc_workspace(self, L_img: int, T: int, C: int, B: int) -> dict:
         p, dev = self.params, self.device
         H, MLP = p.hidden_size, p.mlp_hidden
         n = B * (C + T + L_img)
         bf = dict(device=dev, dtype=torch.bfloat16)
         f32 = dict(device=dev, dtype=torch.float32)
-        self.X = torch.zeros(n, H, device=dev, dtype=self.residual_dtype)
-        self.XM = torch.zeros(n, H, **bf)
-        self.QKV = torch.zeros(n, 3 * H, **bf)
-        self.ATT = torch.zeros(n, H, **bf)
-        self.HID = torch.zeros(n, MLP, **bf)
-        self.CAT = torch.zeros(B * (T + L_img), H + MLP, **bf)
-        self.QPRE = torch.zeros(n, H, **bf)
-        self.ATT32 = torch.zeros(max(B * C, 1), H, **f32)  # fp32 copy of the concept attention rows
-        self.TXT_IN = torch.zeros(B * (C + T), p.context_in_dim, **bf)
-        self.PRED = torch.zeros(B * L_img, p.in_channels, **bf)
-        self.ROPE = torch.zeros(n, 64, 2, **f32)
-        self.TEMB = torch.zeros(2 * B, 256, **f32)      # rows 2j / 2j+1: item j's vec / concept_vec chain
-        self.TVAL = torch.zeros(2 * B, **f32)
-        self.YIN = torch.zeros(2 * B, p.vec_in_dim, **f32)
-        self.HVEC = torch.zeros(2 * B, H, **f32)
-        self.VEC = torch.zeros(2 * B, H, **f32)
-        self.MOD = torch.zeros(B, 2, self.weights.mod_rows, **f32)
-        self.LOGITS = torch.zeros(max(C, 1), L_img, **f32)
+        ws = dict(
+            X=torch.zeros(n, H, device=dev, dtype=self.residual_dtype),
+            XM=torch.zeros(n, H, **bf),
+            QKV=torch.zeros(n, 3 * H, **bf),
+            ATT=torch.zeros(n, H, **bf),
+            HID=torch.zeros(n, MLP, **bf),
+            CAT=torch.zeros(B * (T + L_img), H + MLP, **bf),
+            # post-QKNorm, pre-RoPE q of the captured layers (cross-attention-space vectors) in fp32: their bf16 rounding
+            # alone was ~half of the cross-space heat-map error (tests/tools/error_budget.py)
+            QPRE=torch.zeros(n, H, **f32),
+            ATT32=torch.zeros(max(B * C, 1), H, **f32),  # fp32 copy of the concept attention rows
+            TXT_IN=torch.zeros(B * (C + T), p.context_in_dim, **bf),
+            PRED=torch.zeros(B * L_img, p.in_channels, **bf),
+            ROPE=torch.zeros(n, 64, 2, **f32),
+            TEMB=torch.zeros(2 * B, 256, **f32),      # rows 2j / 2j+1: item j's vec / concept_vec chain
+            TVAL=torch.zeros(2 * B, **f32),
+            YIN=torch.zeros(2 * B, p.vec_in_dim, **f32),
+            HVEC=torch.zeros(2 * B, H, **f32),
+            VEC=torch.zeros(2 * B, H, **f32),
+            MOD=torch.zeros(B, 2, self.weights.mod_rows, **f32),
+            LOGITS=torch.zeros(max(C, 1), L_img, **f32))
         if self.precision == "fp8":   # e4m3 images of the GEMM inputs + one fp32 scale per row
             u8 = dict(device=dev, dtype=torch.uint8)
-            self.XM8, self.XMS = torch.zeros(n, H, **u8), torch.zeros(n, **f32)
-            self.ATT8, self.ATTS = torch.zeros(n, H, **u8), torch.zeros(n, **f32)
-            self.HID8, self.HIDS = torch.zeros(n, MLP, **u8), torch.zeros(n, **f32)
-            self.CAT8, self.CATS = torch.zeros(B * (T + L_img), H + MLP, **u8), torch.zeros(B * (T + L_img), **f32)
-        self._ws_key = key
-        self._rope_key = None
+            ws.update(XM8=torch.zeros(n, H, **u8), XMS=torch.zeros(n, **f32),
+                      ATT8=torch.zeros(n, H, **u8), ATTS=torch.zeros(n, **f32),
+                      HID8=torch.zeros(n, MLP, **u8), HIDS=torch.zeros(n, **f32),
+                      CAT8=torch.zeros(B * (T + L_img), H + MLP, **u8), CATS=torch.zeros(B * (T + L_img), **f32))
+        return ws
 
     def _rope_table(self, img_ids, txt_ids, concept_ids, C, T):
         """(cos, sin) per row in [concept | text | image] order.  rope(): angles in float64,
@@ -516,6 +539,10 @@ class HipFluxDiT:
         self._modulation_rows(self.VEC[:mod2.shape[0]], mod2)
         self._mod_cur = self.MOD
 
+    def _q_out_scale(self) -> float:
+        """What the qkv epilogue multiplies the rotated q by: softmax_scale * log2(e) (head_dim 128), or 0 (= 1)."""
+        return (1.0 / math.sqrt(128.0)) * 1.4426950408889634 if self.prescale_q else 0.0
+
     def _double_block(self, i, g, joint_attention_kwargs=None, out=None, return_vectors=False, heatmaps=None):
         """ModifiedDoubleStreamBlock.forward (modified_double_stream_block.py:69-204) on the resident X rows
         [concepts | text | image] of all work items; 7 launches."""
@@ -560,12 +587,12 @@ class HipFluxDiT:
                              W.tensors.get(b + "img_attn.qkv.bias"), QKV[oI:],
                              L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
                              norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[oI:],
-                             q_prerope=None if qpre is None else qpre[oI:]),
+                             q_prerope=None if qpre is None else qpre[oI:], q_out_scale=self._q_out_scale()),
                            G(fp8, XM[:oI], rows(XM8, 0, oI), rows(XMS, 0, oI), b + "txt_attn.qkv.weight",
                              W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:oI],
                              L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
                              norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:oI],
-                             q_prerope=None if qpre is None else qpre[:oI])])
+                             q_prerope=None if qpre is None else qpre[:oI], q_out_scale=self._q_out_scale())])
         # K8+K9: per item, joint text+image attention and the concept rows; one launch (concept problems first)
         probs = []
         for j in range(B):
@@ -583,7 +610,7 @@ class HipFluxDiT:
         for j in range(B):
             tj, ij = slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)
             probs.append(ops.Attn(qs[tj], ATT[tj], ks[tj], vs[tj], ks[ij], vs[ij], q1=qs[ij], out1=ATT[ij]))
-        ops.attention(probs, NH)
+        ops.attention(probs, NH, q_prescaled=self.prescale_q)
         if capture:
             self._capture(out, i, g, NH, return_vectors, heatmaps)
         if fp8:
@@ -636,13 +663,14 @@ class HipFluxDiT:
             ops.ln_modulate(xs, xms, segs)
         self._launch_gemm([G(fp8, xms, xm8, xms8, b + "linear1.weight", W[b + "linear1.bias"], qkvs,
                              L.EPI_QKV_NORM_ROPE, out2=CAT[:, H:], n_split=3 * H, norm_q=W[b + "norm.query_norm.scale"],
-                             norm_k=W[b + "norm.key_norm.scale"], rope=self.ROPE[oT:])])
+                             norm_k=W[b + "norm.key_norm.scale"], rope=self.ROPE[oT:],
+                             q_out_scale=self._q_out_scale())])
         qh, kh, vh, oh = qkvs[:, :H], qkvs[:, H:2 * H], qkvs[:, 2 * H:], CAT[:, :H]
         probs = []
         for j in range(B):
             tj, ij = slice(j * T, (j + 1) * T), slice(nT + j * Li, nT + (j + 1) * Li)
             probs.append(ops.Attn(qh[tj], oh[tj], kh[tj], vh[tj], kh[ij], vh[ij], q1=qh[ij], out1=oh[ij]))
-        ops.attention(probs, NH)
+        ops.attention(probs, NH, q_prescaled=self.prescale_q)
         if fp8:
             ops.quantize_rows_fp8(CAT, self.CAT8, self.CATS)
         gate = self._mod(m, 0, 2)
@@ -681,7 +709,8 @@ class HipFluxDiT:
             # self-attention-only ablation it rebinds concept_q to the post-RoPE tensor (:140), which
             # for the all-zero concept ids is the same values.  (clone, not .contiguous(): for C = 1 the permuted
             # view already counts as contiguous and would keep aliasing QPRE, which the next block overwrites)
+            # (QPRE is fp32 on the device; the dict carries the activations' dtype, as the reference's does)
             out["cross_attention_concept_vectors"].append(
-                QPRE[:oT].view(B, C, NH, 128).permute(0, 2, 1, 3).clone(memory_format=cf))
+                QPRE[:oT].view(B, C, NH, 128).permute(0, 2, 1, 3).to(torch.bfloat16, memory_format=cf, copy=True))
             out["cross_attention_image_vectors"].append(
-                QPRE[oI:].view(B, Li, NH, 128).permute(0, 2, 1, 3).clone(memory_format=cf))
+                QPRE[oI:].view(B, Li, NH, 128).permute(0, 2, 1, 3).to(torch.bfloat16, memory_format=cf, copy=True))

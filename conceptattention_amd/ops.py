@@ -50,7 +50,8 @@ class Gemm:
     norm_q: Optional[torch.Tensor] = None  # QKV_NORM_ROPE: bf16 [128] scales, fp32 [M,64,2] rope table,
     norm_k: Optional[torch.Tensor] = None  # optional bf16 [M, heads*128] pre-RoPE q output
     rope: Optional[torch.Tensor] = None
-    q_prerope: Optional[torch.Tensor] = None
+    q_prerope: Optional[torch.Tensor] = None   # bf16 or fp32 [M, heads*128]
+    q_out_scale: float = 0.0                   # QKV_NORM_ROPE: rotated q times this before rounding (0 = 1)
     a_scale: Optional[torch.Tensor] = None  # fp8 mode: a, w are uint8 (e4m3 bytes) with fp32 row scales
     w_scale: Optional[torch.Tensor] = None  # ([M] and [N]); the launch then goes to ca_gemm_fp8
     # batched forward: rows < gate_rows are items of gate_item_rows rows, the others items of gate2_item_rows rows;
@@ -101,8 +102,12 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
             if tuple(rope.shape) != (p.M, 64, 2) or not rope.is_contiguous():
                 raise ValueError(f"gemm[{i}]: rope must be contiguous [M,64,2]")
             p.rope, p.n_split = rope.data_ptr(), g.n_split
+            p.q_out_scale = float(g.q_out_scale)
             if g.q_prerope is not None:
-                p.q_prerope, p.ldp = _chk(g.q_prerope, torch.bfloat16, "q_prerope").data_ptr(), g.q_prerope.stride(0)
+                if g.q_prerope.dtype not in (torch.bfloat16, torch.float32):
+                    raise ValueError(f"gemm[{i}]: q_prerope must be bf16 or fp32")
+                p.q_prerope, p.ldp = _chk(g.q_prerope, g.q_prerope.dtype, "q_prerope").data_ptr(), g.q_prerope.stride(0)
+                p.qpre_f32 = int(g.q_prerope.dtype == torch.float32)
             if g.out2 is not None:
                 p.out2, p.ld2 = _chk(g.out2, torch.bfloat16, "out2").data_ptr(), g.out2.stride(0)
         elif g.epilogue == L.EPI_SPLIT_GELU:
@@ -159,7 +164,9 @@ class Attn:
     out1: Optional[torch.Tensor] = None
 
 
-def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] = None) -> None:
+def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] = None,
+              q_prescaled: bool = False) -> None:
+    """``q_prescaled``: the q rows already carry softmax_scale * log2(e) (Gemm.q_out_scale; CA_ATTN_Q_PRESCALED)."""
     lib = L.load()
     arr = (L.AttnProblem * len(problems))()
     for i, a in enumerate(problems):
@@ -188,8 +195,14 @@ def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] =
             if a.out_f32.shape[0] != p.nq:
                 raise ValueError(f"attention[{i}]: out_f32 row mismatch")
             p.out_f32, p.ldo32 = a.out_f32.data_ptr(), a.out_f32.stride(0)
-    if scale is None:
+    if q_prescaled:
+        if scale is not None:
+            raise ValueError("attention: give either scale or q_prescaled")
+        scale = L.ATTN_Q_PRESCALED
+    elif scale is None:
         scale = 1.0 / math.sqrt(128.0)
+    elif not scale > 0:
+        raise ValueError("attention: scale must be > 0")
     if _attn_hook is not None:
         _attn_hook(arr, num_heads, lambda: L.check(lib.ca_attn_fwd_bf16(arr, len(problems), num_heads, scale,
                                                                           _stream()), "ca_attn_fwd_bf16"))
@@ -331,18 +344,20 @@ def modulation_gemm(vecs, w, bias, out, ones) -> bool:
 
 
 def heatmap_logits(img_vec, con_vec, logits) -> None:
-    """logits[c,p] = <img_vec[p,:], con_vec[c,:]>; img bf16 [L,dim], con bf16|fp32 [C,dim] -> fp32 [C,L]."""
+    """logits[c,p] = <img_vec[p,:], con_vec[c,:]>; img bf16|fp32 [L,dim], con bf16|fp32 [C,dim] -> fp32 [C,L]
+    (fp32 image vectors go with fp32 concept vectors)."""
     lib = L.load()
-    _chk(img_vec, torch.bfloat16, "img_vec")
-    if con_vec.dtype not in (torch.bfloat16, torch.float32):
-        raise ValueError("heatmap_logits: con_vec must be bf16 or fp32")
+    if img_vec.dtype not in (torch.bfloat16, torch.float32) or con_vec.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("heatmap_logits: img_vec and con_vec must be bf16 or fp32")
+    _chk(img_vec, img_vec.dtype, "img_vec")
     _chk(con_vec, con_vec.dtype, "con_vec")
     _chk(logits, torch.float32, "logits")
     Lp, dim, Cc = img_vec.shape[0], img_vec.shape[1], con_vec.shape[0]
     if tuple(logits.shape) != (Cc, Lp) or not logits.is_contiguous() or con_vec.shape[1] != dim:
         raise ValueError("heatmap_logits: shape mismatch")
     L.check(lib.ca_heatmap_logits_bf16(img_vec.data_ptr(), img_vec.stride(0), con_vec.data_ptr(), con_vec.stride(0),
-                                       int(con_vec.dtype == torch.float32), Lp, Cc, dim, logits.data_ptr(),
+                                       int(con_vec.dtype == torch.float32) | 2 * int(img_vec.dtype == torch.float32),
+                                       Lp, Cc, dim, logits.data_ptr(),
                                        _stream()), "ca_heatmap_logits_bf16")
 
 

@@ -281,7 +281,7 @@ class ConceptAttentionFluxPipeline:
     @on_own_device
     def layer_noise_sweep_on_device(self, latent, txt, vec, concept_embeddings, noise_levels, num_steps: int = 50,
                                     layer_indices=None, seed: int = 0, num_samples: int = 1,
-                                    rank: int = 0, world: int = 1):
+                                    rank: int = 0, world: int = 1, batch: int = 1):
         """Concept maps per (noise level, double block): the workload of the reference's per-layer /
         per-timestep segmentation sweeps (experiments/per_layer_segmentation/test_segmentations_per_layer.py:
         104-114,164-189; experiments/per_timestep_segmentation/test_segmentations_per_time.py:75-104) without
@@ -289,6 +289,8 @@ class ConceptAttentionFluxPipeline:
         blocks from x = t*noise + (1-t)*latent (concept_attention/segmentation.py:85-113), so the levels shard
         over ranks: this rank computes levels rank, rank+world, ...; rows of other ranks stay
         zero and one all_reduce(sum) (distributed.allreduce_sum_) or all_gather completes the table.
+        ``batch`` levels at a time share one forward (each level is a work item with its own timestep; per level
+        bit-identical to batch = 1).
         noise_levels: indices into get_schedule(num_steps).  Returns (out_space, cross_space), each
         fp32 [len(noise_levels), len(layer_indices), C, side, side]."""
         layer_indices = list(range(self.params.depth)) if layer_indices is None else [int(l) for l in layer_indices]
@@ -302,20 +304,28 @@ class ConceptAttentionFluxPipeline:
         out = torch.zeros(nl, nlay, C, n_patches, device=self.device)
         cross = torch.zeros(nl, nlay, C, n_patches, device=self.device)
         height, width = latent.shape[-2] * 8, latent.shape[-1] * 8
-        for li in range(rank, nl, world):
-            t = schedule[int(noise_levels[li])]
-            req = HeatmapRequest(tuple(layer_indices), 0.0, torch.zeros(C, n_patches, device=self.device),
-                                 torch.zeros(C, n_patches, device=self.device), per_layer_out=out[li],
-                                 per_layer_cross=cross[li], per_layer_weight=1.0 / num_samples)
+        batch = max(1, min(batch, _lib.ATTN_MAX_PROBLEMS // 2, _lib.MAX_SEGMENTS // 3))
+        mine = list(range(rank, nl, world))
+        for g0 in range(0, len(mine), batch):
+            grp = mine[g0:g0 + batch]
+            B = len(grp)
+            ts = [schedule[int(noise_levels[li])] for li in grp]
+            reqs = [HeatmapRequest(tuple(layer_indices), 0.0, torch.zeros(C, n_patches, device=self.device),
+                                   torch.zeros(C, n_patches, device=self.device), per_layer_out=out[li],
+                                   per_layer_cross=cross[li], per_layer_weight=1.0 / num_samples) for li in grp]
+
+            def rep(t):   # the B levels are B work items of the same image
+                return t if B == 1 else t.expand(B, *t.shape[1:]).contiguous()
             for s_i in range(num_samples):
                 noise = sampling.get_noise(1, height, width, self.device, torch.bfloat16, seed + s_i)
-                x = (t * noise.float() + (1.0 - t) * latent.float()).to(torch.bfloat16)
-                inp = sampling.prepare_from_embeddings(x, txt, vec)
+                x = torch.cat([(t * noise.float() + (1.0 - t) * latent.float()).to(torch.bfloat16) for t in ts], 0)
+                inp = sampling.prepare_from_embeddings(x, rep(txt), rep(vec))
+                cB, idB, vB = sampling.concept_inputs(rep(con), rep(vec))
                 self.model(img=inp["img"], img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
-                           concepts=con, concept_ids=con_ids, concept_vec=con_vec, y=con_vec,
-                           timesteps=torch.full((1,), t, device=self.device),
-                           guidance=torch.zeros(1, device=self.device), stop_after_multimodal_attentions=True,
-                           return_vectors=False, heatmaps=req)
+                           concepts=cB, concept_ids=idB, concept_vec=vB, y=vB,
+                           timesteps=torch.tensor(ts, device=self.device, dtype=torch.float32),
+                           guidance=torch.zeros(B, device=self.device), stop_after_multimodal_attentions=True,
+                           return_vectors=False, heatmaps=reqs)
         return out.view(nl, nlay, C, side, side), cross.view(nl, nlay, C, side, side)
 
     # ------------------------------------------------------------------ encode_image (:204-357)
@@ -326,11 +336,12 @@ class ConceptAttentionFluxPipeline:
                      noise_timestep: int = 2, device: str = "cuda:0", return_pil_heatmaps: bool = True,
                      seed: int = 0, cmap="plasma", stop_after_multi_modal_attentions=True,
                      attention_norm: str = "sparsemax", softmax=True,
-                     joint_attention_kwargs=None) -> ConceptAttentionPipelineOutput:
+                     joint_attention_kwargs=None, noise=None) -> ConceptAttentionPipelineOutput:
         """``image``: a latent tensor (1,16,h/8,w/8), or a PIL image when an autoencoder was injected.
         One forward of the 19 double blocks per noise sample (stop_after_multimodal_attentions).
         ``joint_attention_kwargs`` (not in the reference's signature, which hard-codes None at :296) lets the
-        segmentation harness select the concept cross/self-attention ablations."""
+        segmentation harness select the concept cross/self-attention ablations; ``noise`` (a list of num_samples
+        tensors shaped like the latent) overrides get_noise, whose device RNG stream differs between platforms."""
         assert all([0 <= li < self.params.depth for li in layer_indices]), "Invalid layer index"
         assert height == width, "Height and width must be the same for now"
         norm = resolve_norm(softmax, attention_norm)
@@ -345,14 +356,18 @@ class ConceptAttentionFluxPipeline:
         txt, vec, con, con_ids, con_vec = self._embed(prompt, concepts)
         out_space, cross_space = self._encode_maps(self.model, latent, txt, vec, con, con_ids, con_vec, layer_indices,
                                                    num_samples, num_steps, noise_timestep, seed,
-                                                   stop_after_multi_modal_attentions, joint_attention_kwargs, norm)
+                                                   stop_after_multi_modal_attentions, joint_attention_kwargs, norm,
+                                                   noise=noise)
         return self._finish(image, out_space, cross_space, return_pil_heatmaps, cmap)
 
     def _encode_maps(self, model, latent, txt, vec, con, con_ids, con_vec, layer_indices, num_samples, num_steps,
                      noise_timestep, seed, stop_after_multi_modal_attentions=True, joint_attention_kwargs=None,
-                     norm: int = 0):
+                     norm: int = 0, noise=None):
         """Device core of encode_image for B images at once (latent (B,16,h,w), txt (B,T,4096), ...): one forward
-        per noise sample on ``model``; returns the two fp32 maps [B, C, side, side]."""
+        per noise sample on ``model``; returns the two fp32 maps [B, C, side, side].  ``noise``: optional list of
+        num_samples tensors (1 or B,16,h,w) used instead of get_noise(seed + i)."""
+        if noise is not None and len(noise) != num_samples:
+            raise ValueError("noise: one tensor per noise sample")
         B, C = con.shape[0], con.shape[1]
         n_patches = (latent.shape[-1] // 2) * (latent.shape[-2] // 2)
         height, width = latent.shape[-2] * 8, latent.shape[-1] * 8
@@ -366,9 +381,10 @@ class ConceptAttentionFluxPipeline:
         schedule = sampling.get_schedule(num_steps, n_patches, shift=(not self.is_schnell))
         for i in range(num_samples):
             # add_noise_to_image (concept_attention/segmentation.py:85-113)
-            noise = sampling.get_noise(1, height, width, self.device, torch.bfloat16, seed + i)
+            nz = (noise[i].to(self.device, torch.bfloat16) if noise is not None
+                  else sampling.get_noise(1, height, width, self.device, torch.bfloat16, seed + i))
             t = schedule[noise_timestep]
-            x = (t * noise.float() + (1.0 - t) * latent.float()).to(torch.bfloat16)
+            x = (t * nz.float() + (1.0 - t) * latent.float()).to(torch.bfloat16)
             inp = sampling.prepare_from_embeddings(x, txt, vec)
             t_vec = torch.full((B,), schedule[noise_timestep], device=self.device)
             model(img=inp["img"], img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
@@ -382,7 +398,8 @@ class ConceptAttentionFluxPipeline:
     @torch.no_grad()
     @on_own_device
     def encode_many_on_device(self, items, n_streams: int = 1, batch: int = 1, layer_indices=list(range(15, 19)),
-                              num_samples: int = 1, num_steps: int = 4, noise_timestep: int = 2, seed: int = 0):
+                              num_samples: int = 1, num_steps: int = 4, noise_timestep: int = 2, seed: int = 0,
+                              noise=None):
         """Batch form of encode_image for independent images (the loop of
         experiments/imagenet_segmentation/run_experiment.py:137; BASELINE.json configs[3]): ``items`` are dicts with
         latent (1,16,h/8,w/8), txt (1,T,4096), vec (1,768), concepts (1,C,4096) already on the device; they are
@@ -412,7 +429,7 @@ class ConceptAttentionFluxPipeline:
                 latent = cat("latent").to(self.device, torch.bfloat16)
                 con, con_ids, con_vec = sampling.concept_inputs(cat("concepts"), cat("vec"))
                 ho, hc = self._encode_maps(self._replicas[slot], latent, cat("txt"), cat("vec"), con, con_ids, con_vec,
-                                           layer_indices, num_samples, num_steps, noise_timestep, seed)
+                                           layer_indices, num_samples, num_steps, noise_timestep, seed, noise=noise)
                 for k, i in enumerate(idx):
                     results[i] = (ho[k:k + 1], hc[k:k + 1])
         for st in self._streams[:n_streams]:

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define CA_VERSION 110 /* 0.1.1: ca_gemm_problem.out_f32, fp32-input LayerNorm, sparse heat-map norms */
+#define CA_VERSION 120 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
+                          CA_ATTN_Q_PRESCALED */
 
 #define CA_OK 0
 #define CA_ERR_ARG (-1)    /* bad shape / null pointer / misalignment */
@@ -89,7 +90,7 @@ typedef struct {
   const void *norm_q;/* bf16 [128] query_norm.scale; QKV_NORM_ROPE only */
   const void *norm_k;/* bf16 [128] key_norm.scale */
   const float *rope; /* fp32 [M,64,2] (cos,sin) for this problem's rows */
-  void *q_prerope;   /* optional bf16 [M, heads*128], row stride ldp: normalised pre-RoPE q */
+  void *q_prerope;   /* optional [M, heads*128], row stride ldp: normalised pre-RoPE q; bf16, or fp32 if qpre_f32 */
   const float *a_scale; /* ca_gemm_fp8 only: fp32 [M], dequantisation scale of each row of A */
   const float *w_scale; /* ca_gemm_fp8 only: fp32 [N], dequantisation scale of each row of W */
   int32_t M, N, K;
@@ -105,6 +106,12 @@ typedef struct {
   int32_t gate_item_rows;  /* rows < gate_rows are consecutive work items of gate_item_rows rows, the others of     */
   int32_t gate2_item_rows; /* gate2_item_rows rows, and item i of a range uses its base vector + i * gate_stride   */
                            /* floats (gate_stride % 4 == 0): every item of a batch has its own adaLN gates         */
+  int32_t qpre_f32;        /* QKV_NORM_ROPE: 1 = q_prerope holds fp32 elements (ldp in elements, % 4 == 0): the    */
+                           /* cross-attention-space vectors of modified_double_stream_block.py:189-190 without     */
+                           /* their bf16 rounding (the heat-map logits are then formed from fp32 q on both sides)  */
+  float q_out_scale;       /* QKV_NORM_ROPE: the rotated q is multiplied by this in fp32 before its ONE rounding   */
+                           /* to bf16 (0 = 1.0; k, v and q_prerope are not scaled).  With softmax_scale * log2(e)  */
+                           /* here, ca_attn_fwd_bf16(scale = CA_ATTN_Q_PRESCALED) needs no per-score multiply      */
 } ca_gemm_problem;
 
 int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile, ca_stream_t stream);
@@ -151,6 +158,10 @@ typedef struct {
   int32_t _pad[3];
 } ca_attn_problem;
 
+/* scale = the softmax scale (1/sqrt(128) at the reference's call sites), or CA_ATTN_Q_PRESCALED when the q rows were
+ * written with softmax_scale * log2(e) already folded in (ca_gemm_problem.q_out_scale): p = exp2(q.k - reference)
+ * then costs no multiply per score. */
+#define CA_ATTN_Q_PRESCALED 0.0f
 int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
                      float scale, ca_stream_t stream);
 
@@ -220,7 +231,8 @@ int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void *W, const v
  *   acc[c,p]   += weight * softmax_c(logits[:,p])        (weight = 1/(|timesteps|*|layers|), :64-82)
  * fp32 accumulation (the reference does this in bf16; see DESIGN.md "tolerance").
  */
-/* con_vec is bf16 [C,dim] (con_is_f32 = 0) or fp32 [C,dim] (con_is_f32 = 1); ldc in elements, a multiple of 4. */
+/* con_is_f32 is a bit set: bit 0 = con_vec is fp32 [C,dim] (else bf16), bit 1 = img_vec is fp32 [L,dim] (else bf16;
+ * needs bit 0 as well); ldi / ldc in elements, multiples of 8 / 4. */
 int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const void *con_vec, int32_t ldc,
                            int32_t con_is_f32, int32_t L, int32_t C, int32_t dim, float *logits,
                            ca_stream_t stream);

@@ -31,9 +31,28 @@ def test_self_launch_two_ranks_prints_one_json_line():
 
 
 def test_self_launch_propagates_child_failure():
-    # a rank that dies (unknown flag -> argparse exit 2 in every child) must make the parent exit non-zero
-    r = _run(["--gpus", "2", "--stub-workload", "--no-such-flag"])
+    # a rank that dies AFTER the launch and the rendezvous must make the parent exit non-zero (the flag is valid, so
+    # the parent's own argparse passes and the children really start)
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--stub-workload", "--stub-fail-rank", "1"])
     assert r.returncode != 0
+    assert "rank 1 fails on request" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]   # no result line from a failed job
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("workload,collective", [("encode", "all_gather"), ("sweep", "all_reduce")])
+def test_self_launch_encode_and_sweep_workloads(workload, collective):
+    """The N-rank entries of BASELINE.json configs[3] (image-sharded encode, one all_gather) and configs[4]
+    (level-sharded sweep, one all_reduce(sum)): launcher, sharding, collective and the JSON line, with stub items."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--stub-workload", "--workload", workload])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["workload"] == workload and out["collective"] == collective
+    assert out["gathered_in_item_order"] is True
 
 
 def test_world_size_mismatch_is_rejected():

@@ -127,6 +127,19 @@ def test_gemm_qkv_norm_rope_epilogue(tail):
     close(out.cpu().view(M, 3, nh, 128)[:, 2], qkv[:, 2], atol=2e-2)
     if tail:
         close(out2.cpu(), torch.nn.functional.gelu(lin[:, 3 * Hd:], approximate="tanh"), atol=2e-2)
+    # fp32 pre-RoPE q (the cross-attention-space vectors without their bf16 rounding) and the rotated q pre-multiplied
+    # by softmax_scale * log2(e) in fp32 before its one rounding; k, v and the bf16 form of q_prerope unchanged.
+    # M = 300 = one full row tile + 44 rows: both the ping-pong and the thin-row kernel's epilogue are exercised.
+    qs = 0.088388347648 * 1.4426950408889634
+    out_s = torch.zeros_like(out)
+    pre32 = torch.zeros(M, Hd, device=DEV, dtype=torch.float32)
+    ops.gemm([ops.Gemm(a, w, b, out_s, L.EPI_QKV_NORM_ROPE, n_split=3 * Hd, norm_q=nq, norm_k=nk, rope=table,
+                       q_prerope=pre32, out2=out2 if tail else None, q_out_scale=qs)])
+    assert torch.equal(pre32.bfloat16(), pre)                        # the same values, rounded once later
+    assert (pre32.cpu() - O.rms_norm(qkv[:, 0], nq.float().cpu()).reshape(M, -1)).abs().max() < 2e-5 * 40
+    assert torch.equal(out_s[:, Hd:], out[:, Hd:])                   # k and v thirds are not scaled
+    roped_q = O.apply_rope(O.rms_norm(qkv[:, 0], nq.float().cpu()).permute(1, 0, 2)[None], cos, sin)[0].permute(1, 0, 2)
+    close(out_s.cpu().view(M, 3, nh, 128)[:, 0], roped_q * qs, atol=2e-3)
     with pytest.raises(ValueError):  # only the 256x256 ping-pong tile carries this epilogue
         ops.gemm([ops.Gemm(a, w, b, out, L.EPI_QKV_NORM_ROPE, n_split=3 * Hd, norm_q=nq, norm_k=nk, rope=table,
                            out2=out2 if tail else None)], L.TILE_PP_256x128)
@@ -292,6 +305,92 @@ def test_attention_online_softmax_rescale_spike():
     out = torch.zeros(nq, 128, device=DEV, dtype=torch.bfloat16)
     ops.attention([ops.Attn(q, out, k, v)], nh)
     close(out, attn_ref(q, k, v, nh), atol=1e-2)
+
+
+@pytest.mark.parametrize("alpha", [1.0, 1.45, 1.9])    # logit gap to the tile-0 reference ~ 16 / 24 / 31 octaves
+@pytest.mark.parametrize("where", ["late_full_tile", "masked_tail_tile", "segment_1", "segment_1_tail"])
+def test_attention_kept_reference_band_spikes(alpha, where):
+    """The softmax reference of a row is set by tile 0 and then KEPT; a tile is redone only when a partial row sum
+    exceeds 2^30.  These spikes sit in the band the 65-octave spike test above does NOT reach: a late key 16-31
+    octaves above the tile-0 reference (alpha * |q|^2 / sqrt(128) * log2 e), i.e. P up to ~2^29 WITHOUT a redo
+    (alpha 1.0, 1.45) and just across the redo limit (1.9) -- in a full tile, in the ragged (masked) last tile, and
+    in the second key segment (its full and its ragged tile).  fp32 reference, the tolerance of the other tests."""
+    nh, nq = 1, 96
+    q = rnd(nq, 128)
+    if where in ("late_full_tile", "masked_tail_tile"):
+        nk = 640 if where == "late_full_tile" else 650           # 650: tile 10 has 10 valid keys
+        k, v = rnd(nk, 128, seed=3), rnd(nk, 128, seed=4)
+        pos = 500 if where == "late_full_tile" else 645
+        k[pos] = (q[17].float() * alpha).bfloat16()
+        k[pos - 130] = (q[70].float() * alpha * 0.9).bfloat16()   # a second row, another wave, another tile
+        probs, kk, vv = (lambda o: [ops.Attn(q, o, k, v)]), k, v
+    else:
+        n0, n1 = 100, 540 if where == "segment_1" else 533       # 633 keys: the last tile is ragged AND in segment 1
+        k0, v0, k1, v1 = rnd(n0, 128, seed=3), rnd(n0, 128, seed=4), rnd(n1, 128, seed=5), rnd(n1, 128, seed=6)
+        pos = 400 if where == "segment_1" else n1 - 3
+        k1[pos] = (q[17].float() * alpha).bfloat16()
+        k1[7] = (q[70].float() * alpha * 0.9).bfloat16()          # tile 1 = the tile that straddles the two segments
+        probs, kk, vv = (lambda o: [ops.Attn(q, o, k0, v0, k1, v1)]), torch.cat((k0, k1)), torch.cat((v0, v1))
+    out = torch.zeros(nq, 128, device=DEV, dtype=torch.bfloat16)
+    ops.attention(probs(out), nh)
+    ref = attn_ref(q, kk, vv, nh)
+    close(out, ref, atol=1e-2)
+    # the spiked rows are (nearly) one-hot on the spike's value row: check them against it directly as well
+    s17 = (q[17].float() @ kk.float().t() / math.sqrt(128)).softmax(0)
+    assert s17.max() > 0.95
+    if s17.max() > 0.995:
+        assert (out[17].float() - vv[int(s17.argmax())].float()).abs().max() < 5e-2
+
+
+@pytest.mark.parametrize("C,T,Limg", [(5, 40, 333), (4, 64, 256), (1, 7, 70)])
+def test_attention_prescaled_q_two_segments_two_problems(C, T, Limg):
+    """CA_ATTN_Q_PRESCALED: q rows that already carry softmax_scale * log2(e) (written so by the qkv epilogue); the
+    kernel's probability is a bare exp2 and every tile's K Q^T chain starts from -reference.  Same result as the
+    scaling kernel on the unscaled q up to q's one rounding; full, ragged and segment-straddling tiles, the concept
+    problem with its fp32 output copy, and a spike that forces the redo path."""
+    nh = 2
+    H = nh * 128
+    buf = rnd(C + T + Limg, 3 * H, scale=1.5)
+    q, k, v = buf[:, :H], buf[:, H:2 * H], buf[:, 2 * H:]
+    k[C + T + Limg // 2, :128] = (q[C + 3, :128].float() * 1.6).bfloat16()    # ~27 octaves above its row's reference
+    sl2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+    qp = (q.float() * sl2).bfloat16()
+    out = torch.zeros(C + T + Limg, H, device=DEV, dtype=torch.bfloat16)
+    out32 = torch.zeros(C, H, device=DEV)
+    main = ops.Attn(qp[C:C + T], out[C:C + T], k[C:C + T], v[C:C + T], k[C + T:], v[C + T:], q1=qp[C + T:],
+                    out1=out[C + T:])
+    con = ops.Attn(qp[:C], out[:C], k[:C], v[:C], k[C + T:], v[C + T:], out_f32=out32)
+    ops.attention([con, main], nh, q_prescaled=True)
+    qe = (qp.float() / sl2)                     # the q the kernel effectively used (exact reference for ITS inputs)
+    close(out[C:], attn_ref(qe[C:], k[C:], v[C:], nh), atol=1e-2)
+    kc, vc = torch.cat((k[:C], k[C + T:])), torch.cat((v[:C], v[C + T:]))
+    close(out[:C], attn_ref(qe[:C], kc, vc, nh), atol=1e-2)
+    assert torch.equal(out32.bfloat16(), out[:C])
+    # against the unscaled path on the original q: only q's rounding differs (2^-9 relative on the logits)
+    out_u = torch.zeros_like(out)
+    ops.attention([ops.Attn(q[:C], out_u[:C], k[:C], v[:C], k[C + T:], v[C + T:]),
+                   ops.Attn(q[C:], out_u[C:], k[C:], v[C:])], nh)
+    assert (out.float() - out_u.float()).abs().max() < 0.1
+    with pytest.raises(ValueError):
+        ops.attention([con], nh, scale=0.1, q_prescaled=True)
+
+
+def test_heatmap_logits_fp32_image_vectors():
+    """fp32 image AND concept vectors (the fp32 q_prerope store): the same k order as the bf16-image form."""
+    Lp, dim, C = 300, 3072, 6
+    iv = torch.randn(Lp, dim, device=DEV)
+    cv = torch.randn(C, dim, device=DEV)
+    lg = torch.zeros(C, Lp, device=DEV)
+    ops.heatmap_logits(iv, cv, lg)
+    ref = (cv.double() @ iv.double().t()).float()
+    assert (lg - ref).abs().max() < 2e-3
+    lg_b = torch.zeros(C, Lp, device=DEV)
+    ops.heatmap_logits(iv.bfloat16(), cv, lg_b)                 # bf16 image vectors: exactly the rounded inputs
+    lg_b32 = torch.zeros(C, Lp, device=DEV)
+    ops.heatmap_logits(iv.bfloat16().float(), cv, lg_b32)
+    assert torch.equal(lg_b, lg_b32)
+    with pytest.raises(ValueError):
+        ops.heatmap_logits(iv, cv.bfloat16(), lg)               # fp32 image vectors go with fp32 concept vectors
 
 
 def test_attention_full_size():

@@ -119,6 +119,13 @@ def test_layer_noise_sweep_matches_oracle(pipe):
     parts = [pipe.layer_noise_sweep_on_device(x["latent"], x["txt"], x["vec"], x["concepts"], levels, num_steps=4,
                                               seed=5, rank=r, world=2)[0] for r in range(2)]
     assert torch.equal(parts[0] + parts[1], out)
+    # several levels per forward (each level = one work item with its own timestep): bit-identical per level
+    lv3 = [0, 1, 3, 2]
+    one = pipe.layer_noise_sweep_on_device(x["latent"], x["txt"], x["vec"], x["concepts"], lv3, num_steps=4, seed=5)
+    many = pipe.layer_noise_sweep_on_device(x["latent"], x["txt"], x["vec"], x["concepts"], lv3, num_steps=4, seed=5,
+                                            batch=3)
+    assert torch.equal(one[0], many[0]) and torch.equal(one[1], many[1])
+    assert torch.equal(one[0][1], out[0]) and torch.equal(one[0][2], out[1])
     # oracle for level index 1 (schedule[3]) with the same noise tensor
     sd = {k: v.float().cpu() for k, v in pipe.model.state_dict().items()}
     sched = sampling.get_schedule(4, 256, shift=False)

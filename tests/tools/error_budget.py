@@ -41,6 +41,10 @@ class Rnd:
     attn: bool = True       # attention output (image/text rows) in bf16
     hid: bool = True        # MLP hidden in bf16
     lin_out: bool = False   # projection outputs rounded before the gated add (the HIP epilogue does NOT: fp32 acc)
+    qpre_img: bool = True   # stored post-QKNorm pre-RoPE image q (cross-space image vectors) in bf16
+    qpre_con: bool = True   # the same for the C concept rows
+    xm_q: bool = True       # the LN-modulate output AS SEEN BY the q third of the qkv projection (a hi+lo bf16 split of
+                            # that operand would make it effectively fp32)
 
 
 def r(x, on):
@@ -61,8 +65,11 @@ def double_block(sd, pfx, nh, img, txt, vec, rope_ti, con, cvec, rope_ci, cfg):
                   O.modulation(sd, pfx + "txt_mod", cvec, 6))
 
     def pre(x, mod, s):
-        xm = r((1 + mod[1]) * O.layer_norm(x) + mod[0], cfg.xm)
+        xm32 = (1 + mod[1]) * O.layer_norm(x) + mod[0]
+        xm = r(xm32, cfg.xm)
         q, k, v = O._split_heads(O.linear(sd, pfx + s + "_attn.qkv", xm), nh)
+        if cfg.xm and not cfg.xm_q:
+            q = O._split_heads(O.linear(sd, pfx + s + "_attn.qkv", xm32), nh)[0]
         return (O.rms_norm(q, sd[pfx + s + "_attn.norm.query_norm.scale"]),
                 O.rms_norm(k, sd[pfx + s + "_attn.norm.key_norm.scale"]), r(v, cfg.qkv))
     iq, ik, iv = pre(img, im, "img")
@@ -77,7 +84,8 @@ def double_block(sd, pfx, nh, img, txt, vec, rope_ti, con, cvec, rope_ci, cfg):
     c_attn32 = sdpa_r(qc[:, :, :C], kc, torch.cat((cv, iv), 2), cfg)   # fp32 copy feeds the maps
     t_attn, i_attn, c_attn32 = map(O._merge_heads, (t_attn, i_attn, c_attn32))
     d = {"output_space_concept_vectors": c_attn32, "output_space_image_vectors": i_attn,
-         "cross_attention_concept_vectors": r(cq, cfg.qkv), "cross_attention_image_vectors": r(iq, cfg.qkv)}
+         "cross_attention_concept_vectors": r(cq, cfg.qkv and cfg.qpre_con),
+         "cross_attention_image_vectors": r(iq, cfg.qkv and cfg.qpre_img)}
 
     def post(x, a, mod, s):
         x = r(x + mod[2] * r(O.linear(sd, pfx + s + "_attn.proj", a), cfg.lin_out), cfg.resid)
@@ -102,7 +110,10 @@ def main():
                 Rnd("fp32_residual", resid=False),
                 Rnd("fp32_residual+fp32_xm", resid=False, xm=False),
                 Rnd("fp32_residual+fp32_p", resid=False, p=False),
-                Rnd("only_residual_bf16", xm=False, qkv=False, p=False, attn=False, hid=False)]
+                Rnd("only_residual_bf16", xm=False, qkv=False, p=False, attn=False, hid=False),
+                Rnd("fp32_residual+fp32_qpre_con", resid=False, qpre_con=False),
+                Rnd("fp32_residual+fp32_qpre", resid=False, qpre_con=False, qpre_img=False),
+                Rnd("fp32_residual+fp32_qpre+split_xm_q", resid=False, qpre_con=False, qpre_img=False, xm_q=False)]
     if len(sys.argv) > 1:
         variants = [v for v in variants if v.name.split("(")[0] in sys.argv[1:]]
     nh = p.num_heads
@@ -116,6 +127,7 @@ def main():
         state[v.name] = [r(O.linear(sd, "img_in", img0), v.resid), r(O.linear(sd, "txt_in", inp["txt"]), v.resid),
                          r(O.linear(sd, "txt_in", inp["concepts"]), v.resid)]
     res = {v.name: {"out": [], "cross": []} for v in variants}
+    mean_cross = {v.name: 0.0 for v in variants}   # mean map over layers 15..18 (what generate_image averages, one step)
     t0 = time.time()
     for i in range(p.depth):
         for v in variants:
@@ -126,17 +138,21 @@ def main():
             ho, hc = layer_maps(d)
             res[v.name]["out"].append(float(np.abs(ho.numpy() - gold_out[i]).max()))
             res[v.name]["cross"].append(float(np.abs(hc.numpy() - gold_cross[i]).max()))
+            if 15 <= i < 19:
+                mean_cross[v.name] = mean_cross[v.name] + (hc.numpy() - gold_cross[i]) / 4.0
         print(f"[{time.time() - t0:5.0f}s] layer {i}: " +
               "  ".join(f"{v.name.split('(')[0]} {res[v.name]['out'][-1]:.2e}/{res[v.name]['cross'][-1]:.2e}"
                         for v in variants), flush=True)
     out = {"note": "max-abs difference of per-layer maps (output space / cross space) from the fp32 oracle, step 0 "
                    "(t=1.0), full size, CPU emulation of the storage roundings", "variants": res,
            "layers_15_18_out": {k: max(v["out"][15:19]) for k, v in res.items()},
-           "layers_15_18_cross": {k: max(v["cross"][15:19]) for k, v in res.items()}}
+           "layers_15_18_cross": {k: max(v["cross"][15:19]) for k, v in res.items()},
+           "mean_map_layers_15_18_cross": {k: float(np.abs(v).max()) for k, v in mean_cross.items()}}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "error_budget.json"), "w"), indent=1)
     print(json.dumps(out["layers_15_18_out"], indent=1))
     print(json.dumps(out["layers_15_18_cross"], indent=1))
+    print(json.dumps(out["mean_map_layers_15_18_cross"], indent=1))
 
 
 if __name__ == "__main__":
