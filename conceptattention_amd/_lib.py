@@ -70,6 +70,11 @@ SIGNATURES = {
                                        C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),
     "ca_ln_modulate_f32in_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                            C.c_int32, C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),
+    "ca_ln_modulate_f32in_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                             C.c_int32, C.c_int32, C.POINTER(ModSegment), C.c_int32, C.c_float,
+                                             C.c_void_p]),
+    "ca_qpre_finish_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_void_p]),
     "ca_quantize_rows_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p]),
     "ca_qknorm_rope_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(NormSegment),

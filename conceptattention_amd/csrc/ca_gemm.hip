@@ -761,7 +761,11 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
 #pragma unroll
           for (int t = 0; t < 8; ++t) y[t] = x[mi][hn][t] * rrms * (float)s8[t];
           if (is_q && P.q_prerope) {
-            if (P.qpre_f32) {
+            if (P.qpre_f32 == 2) {   // the projection itself (bias included), before the norm: ca_qpre_finish_f32
+              float *qp = (float *)P.q_prerope + (size_t)m * P.ldp + head_col + cih;
+              *(f32x4 *)qp = f32x4{x[mi][hn][0], x[mi][hn][1], x[mi][hn][2], x[mi][hn][3]};
+              *(f32x4 *)(qp + 4) = f32x4{x[mi][hn][4], x[mi][hn][5], x[mi][hn][6], x[mi][hn][7]};
+            } else if (P.qpre_f32) {
               float *qp = (float *)P.q_prerope + (size_t)m * P.ldp + head_col + cih;
               *(f32x4 *)qp = f32x4{y[0], y[1], y[2], y[3]};
               *(f32x4 *)(qp + 4) = f32x4{y[4], y[5], y[6], y[7]};
@@ -1138,7 +1142,11 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) y[t] = x[mi][t] * rrms * (float)s8[t];
       if (is_q && P.q_prerope) {
-        if (P.qpre_f32) {
+        if (P.qpre_f32 == 2) {
+          float *qp = (float *)P.q_prerope + (size_t)m * P.ldp + head_col + cih;
+          *(f32x4 *)qp = f32x4{x[mi][0], x[mi][1], x[mi][2], x[mi][3]};
+          *(f32x4 *)(qp + 4) = f32x4{x[mi][4], x[mi][5], x[mi][6], x[mi][7]};
+        } else if (P.qpre_f32) {
           float *qp = (float *)P.q_prerope + (size_t)m * P.ldp + head_col + cih;
           *(f32x4 *)qp = f32x4{y[0], y[1], y[2], y[3]};
           *(f32x4 *)(qp + 4) = f32x4{y[4], y[5], y[6], y[7]};
@@ -1441,7 +1449,7 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
       case CA_EPI_QKV_NORM_ROPE:
         if (tile != CA_TILE_PP_256x256 || p.n_split <= 0 || p.n_split % 768 || p.n_split > p.N || !p.norm_q ||
             !p.norm_k || !p.rope || (p.n_split < p.N && (!p.out2 || p.ld2 % 8 || p.ld2 < p.N - p.n_split)) ||
-            p.ldc < p.n_split || (p.q_prerope && (p.ldp % (p.qpre_f32 ? 4 : 8) || p.ldp < p.n_split / 3)) ||
+            p.ldc < p.n_split || (p.q_prerope && (p.ldp % (p.qpre_f32 ? 4 : 8) || p.ldp < p.n_split / 3 || p.qpre_f32 < 0 || p.qpre_f32 > 2)) ||
             (((uintptr_t)p.norm_q | (uintptr_t)p.norm_k | (uintptr_t)p.rope | (uintptr_t)p.q_prerope |
               (uintptr_t)p.out2) & 15)) {
           ca_set_error("%s[%d]: QKV_NORM_ROPE needs the 256x256 ping-pong tile, n_split = 3*heads*128 <= N, "

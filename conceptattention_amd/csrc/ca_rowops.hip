@@ -46,11 +46,15 @@ __device__ __forceinline__ uint2 ca_pack_fp8x8(const float *y) {
 
 // FP8: the modulated row is quantised to e4m3 with one absmax scale per row (out8 row stride ldo BYTES,
 // out_scale[row] = absmax / 448): the A operand of ca_gemm_fp8.
-template <bool FP8, typename XT = bf16>
+// LO (bf16 output only): a second plane out_lo = bf16(y - float(bf16(y))), the part of the modulated row its bf16
+// rounding drops; out + out_lo carries ~16 mantissa bits (the q projection of the layers whose cross-attention-space
+// vectors are captured is corrected with a product of this plane).
+template <bool FP8, typename XT = bf16, bool LO = false>
 __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const XT *__restrict__ x, int ldx,
                                                              void *__restrict__ out_, int ldo, int M, int H,
                                                              float eps, float *__restrict__ out_scale,
-                                                             const LnArgs A) {
+                                                             const LnArgs A, bf16 *__restrict__ out_lo = nullptr,
+                                                             int ldlo = 0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -127,10 +131,18 @@ __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const XT *__restric
 #pragma unroll
     for (int c = 0; c < LN_MAXCH; ++c) {
       const int k = c * 512 + lane * 8;
-      if (k < H)
+      if (k < H) {
         *(uint4 *)((bf16 *)out_ + (size_t)row * ldo + k) =
             make_uint4(ca_pack2(v[c][0], v[c][1]), ca_pack2(v[c][2], v[c][3]), ca_pack2(v[c][4], v[c][5]),
                        ca_pack2(v[c][6], v[c][7]));
+        if constexpr (LO) {
+          float r[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) r[j] = v[c][j] - (float)(bf16)v[c][j];
+          *(uint4 *)(out_lo + (size_t)row * ldlo + k) =
+              make_uint4(ca_pack2(r[0], r[1]), ca_pack2(r[2], r[3]), ca_pack2(r[4], r[5]), ca_pack2(r[6], r[7]));
+        }
+      }
     }
   }
   if constexpr (FP8) {
@@ -309,6 +321,43 @@ __global__ __launch_bounds__(256) void ca_gemv_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Per (row, head): y = (x + d) * rsqrt(mean((x + d)^2) + 1e-6) * scale, in place on x (fp32).  x = the q third of a qkv
+// projection before its RMS norm (what CA_EPI_QKV_NORM_ROPE stores to q_prerope with qpre_f32 = 2), d = the product
+// of the LayerNorm output's low plane with the same weights: the sum is the projection of the UNROUNDED LayerNorm
+// output to ~16 mantissa bits.  16 lanes per (row, head), 8 columns each.
+__global__ __launch_bounds__(256) void ca_qpre_finish_kernel(float *__restrict__ x, int ldx, const float *__restrict__ d,
+                                                             int ldd, const bf16 *__restrict__ scale, int M, int heads) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long unit = gid >> 4;           // (row, head)
+  const int t16 = (int)(gid & 15);
+  if (unit >= (long)M * heads) return;  // (whole 16-lane groups leave together: M * heads units of 16 lanes)
+  const int row = (int)(unit / heads), head = (int)(unit % heads);
+  float *xp = x + (size_t)row * ldx + head * 128 + t16 * 8;
+  f32x4 a0 = *(const f32x4 *)xp, a1 = *(const f32x4 *)(xp + 4);
+  if (d) {
+    const float *dp = d + (size_t)row * ldd + head * 128 + t16 * 8;
+    const f32x4 b0 = *(const f32x4 *)dp, b1 = *(const f32x4 *)(dp + 4);
+    a0 += b0;
+    a1 += b1;
+  }
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sq = fmaf(a0[j], a0[j], fmaf(a1[j], a1[j], sq));
+  sq += __shfl_xor(sq, 1);
+  sq += __shfl_xor(sq, 2);
+  sq += __shfl_xor(sq, 4);
+  sq += __shfl_xor(sq, 8);
+  const float rrms = rsqrtf(fmaf(sq, 1.0f / 128.0f, 1e-6f));
+  const bf16x8 s8 = *(const bf16x8 *)(scale + t16 * 8);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a0[j] = a0[j] * rrms * (float)s8[j];
+    a1[j] = a1[j] * rrms * (float)s8[4 + j];
+  }
+  *(f32x4 *)xp = a0;
+  *(f32x4 *)(xp + 4) = a1;
+}
+
 // logits[c,p] = <img_vec[p,:], con_vec[c,:]> for CC concepts per pass; one wave per patch.
 // The concept vectors sit in LDS as fp32 (they are either bf16 or already fp32 in HBM).
 template <int CC, typename CT, typename IT = bf16>
@@ -505,8 +554,12 @@ int check_launch(const char *what) {
 namespace {
 int ln_modulate_impl(const char *FN, const void *x, int32_t ldx, void *out, int32_t ldo, float *out_scale, int32_t M,
                      int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream,
-                     bool x_f32 = false) {
+                     bool x_f32 = false, void *out_lo = nullptr, int32_t ldlo = 0) {
   const bool fp8 = out_scale != nullptr;
+  if (out_lo && (fp8 || !x_f32 || ldlo % 8 || ldlo < H || ((uintptr_t)out_lo & 15))) {
+    ca_set_error("%s: the low plane needs an fp32 input, a bf16 output, ldlo %% 8 == 0 and ldlo >= H", FN);
+    return CA_ERR_ARG;
+  }
   if (!x || !out || !segs || M < 1 || H < 8 || H % 8 || H > LN_MAXCH * 512 || n_segs < 1 ||
       n_segs > CA_MAX_SEGMENTS || ldx % (x_f32 ? 4 : 8) || ldo % (fp8 ? 16 : 8) || ldx < H || ldo < H ||
       (((uintptr_t)x | (uintptr_t)out) & 15) || ((uintptr_t)out_scale & 3)) {
@@ -532,7 +585,10 @@ int ln_modulate_impl(const char *FN, const void *x, int32_t ldx, void *out, int3
   }
   const dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (x_f32 && fp8)
+  if (out_lo)
+    hipLaunchKernelGGL((ca_ln_modulate_kernel<false, float, true>), grid, block, 0, st, (const float *)x, ldx, out, ldo,
+                       M, H, eps, (float *)nullptr, A, (bf16 *)out_lo, ldlo);
+  else if (x_f32 && fp8)
     hipLaunchKernelGGL((ca_ln_modulate_kernel<true, float>), grid, block, 0, st, (const float *)x, ldx, out, ldo, M, H,
                        eps, out_scale, A);
   else if (x_f32)
@@ -566,6 +622,17 @@ extern "C" int ca_ln_modulate_fp8(const void *x, int32_t ldx, void *out8, int32_
 extern "C" int ca_ln_modulate_f32in(const float *x, int32_t ldx, void *out, int32_t ldo, int32_t M, int32_t H,
                                     const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream) {
   return ln_modulate_impl("ca_ln_modulate_f32in", x, ldx, out, ldo, nullptr, M, H, segs, n_segs, eps, stream, true);
+}
+
+extern "C" int ca_ln_modulate_f32in_split(const float *x, int32_t ldx, void *out, int32_t ldo, void *out_lo,
+                                          int32_t ldlo, int32_t M, int32_t H, const ca_mod_segment *segs,
+                                          int32_t n_segs, float eps, ca_stream_t stream) {
+  if (!out_lo) {
+    ca_set_error("ca_ln_modulate_f32in_split: out_lo is NULL");
+    return CA_ERR_ARG;
+  }
+  return ln_modulate_impl("ca_ln_modulate_f32in_split", x, ldx, out, ldo, nullptr, M, H, segs, n_segs, eps, stream,
+                          true, out_lo, ldlo);
 }
 
 extern "C" int ca_ln_modulate_f32in_fp8(const float *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale,
@@ -695,6 +762,19 @@ extern "C" int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const vo
     if (rc) return rc;
   }
   return CA_OK;
+}
+
+extern "C" int ca_qpre_finish_f32(float *x, int32_t ldx, const float *d, int32_t ldd, const void *norm_scale, int32_t M,
+                                  int32_t heads, ca_stream_t stream) {
+  if (!x || !norm_scale || M < 1 || heads < 1 || ldx % 4 || ldx < heads * 128 || (d && (ldd % 4 || ldd < heads * 128)) ||
+      (((uintptr_t)x | (uintptr_t)d | (uintptr_t)norm_scale) & 15)) {
+    ca_set_error("ca_qpre_finish_f32: bad arguments (M=%d heads=%d ldx=%d ldd=%d)", M, heads, ldx, ldd);
+    return CA_ERR_ARG;
+  }
+  const long threads = (long)M * heads * 16;
+  hipLaunchKernelGGL(ca_qpre_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, ldx, d, ldd, (const bf16 *)norm_scale, M, heads);
+  return check_launch("ca_qpre_finish_f32");
 }
 
 extern "C" int ca_heatmap_softmax_accumulate(const float *logits, int32_t C, int32_t L, float weight, float *acc,

@@ -52,6 +52,7 @@ class Gemm:
     rope: Optional[torch.Tensor] = None
     q_prerope: Optional[torch.Tensor] = None   # bf16 or fp32 [M, heads*128]
     q_out_scale: float = 0.0                   # QKV_NORM_ROPE: rotated q times this before rounding (0 = 1)
+    qpre_raw: bool = False                     # fp32 q_prerope receives the projection BEFORE its norm (qpre_finish)
     a_scale: Optional[torch.Tensor] = None  # fp8 mode: a, w are uint8 (e4m3 bytes) with fp32 row scales
     w_scale: Optional[torch.Tensor] = None  # ([M] and [N]); the launch then goes to ca_gemm_fp8
     # batched forward: rows < gate_rows are items of gate_item_rows rows, the others items of gate2_item_rows rows;
@@ -108,6 +109,10 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
                     raise ValueError(f"gemm[{i}]: q_prerope must be bf16 or fp32")
                 p.q_prerope, p.ldp = _chk(g.q_prerope, g.q_prerope.dtype, "q_prerope").data_ptr(), g.q_prerope.stride(0)
                 p.qpre_f32 = int(g.q_prerope.dtype == torch.float32)
+                if g.qpre_raw:
+                    if not p.qpre_f32:
+                        raise ValueError(f"gemm[{i}]: qpre_raw needs an fp32 q_prerope")
+                    p.qpre_f32 = 2
             if g.out2 is not None:
                 p.out2, p.ld2 = _chk(g.out2, torch.bfloat16, "out2").data_ptr(), g.out2.stride(0)
         elif g.epilogue == L.EPI_SPLIT_GELU:
@@ -219,9 +224,10 @@ def set_attn_hook(hook) -> None:
     _attn_hook = hook
 
 
-def ln_modulate(x, out, segments, eps: float = 1e-6, out_scale=None) -> None:
+def ln_modulate(x, out, segments, eps: float = 1e-6, out_scale=None, out_lo=None) -> None:
     """segments: [(row_end, shift fp32[H], scale fp32[H]), ...] covering all rows of x.
-    With ``out`` uint8 and ``out_scale`` fp32 [M] the result is quantised to e4m3 per row (ca_ln_modulate_fp8)."""
+    With ``out`` uint8 and ``out_scale`` fp32 [M] the result is quantised to e4m3 per row (ca_ln_modulate_fp8).
+    ``out_lo`` (bf16, fp32 input only): second plane bf16(y - float(bf16(y))) (ca_ln_modulate_f32in_split)."""
     lib = L.load()
     fp8 = out.dtype == torch.uint8
     x32 = x.dtype == torch.float32   # fp32 residual stream
@@ -241,9 +247,33 @@ def ln_modulate(x, out, segments, eps: float = 1e-6, out_scale=None) -> None:
         L.check(fn(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), out_scale.data_ptr(),
                    x.shape[0], x.shape[1], arr, len(segments), eps, _stream()), "ca_ln_modulate_fp8")
         return
+    if out_lo is not None:
+        if not x32:
+            raise ValueError("ln_modulate: out_lo needs an fp32 input")
+        _chk(out_lo, torch.bfloat16, "out_lo")
+        if out_lo.shape != out.shape:
+            raise ValueError("ln_modulate: out_lo must have out's shape")
+        L.check(lib.ca_ln_modulate_f32in_split(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
+                                               out_lo.data_ptr(), out_lo.stride(0), x.shape[0], x.shape[1], arr,
+                                               len(segments), eps, _stream()), "ca_ln_modulate_f32in_split")
+        return
     fn = lib.ca_ln_modulate_f32in if x32 else lib.ca_ln_modulate_bf16
     L.check(fn(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
                arr, len(segments), eps, _stream()), "ca_ln_modulate_bf16")
+
+
+def qpre_finish(x, d, norm_scale, num_heads: int) -> None:
+    """x <- RMSNorm_128(x + d) * norm_scale per (row, head), in place; x, d fp32 [M, heads*128] (d may be None)."""
+    lib = L.load()
+    _chk(x, torch.float32, "x"), _chk(norm_scale, torch.bfloat16, "norm_scale")
+    if d is not None:
+        _chk(d, torch.float32, "d")
+        if d.shape != x.shape:
+            raise ValueError("qpre_finish: d must have x's shape")
+    if x.dim() != 2 or x.shape[1] != num_heads * 128 or norm_scale.numel() != 128:
+        raise ValueError("qpre_finish: x must be [M, heads*128], norm_scale [128]")
+    L.check(lib.ca_qpre_finish_f32(x.data_ptr(), x.stride(0), _ptr(d), 0 if d is None else d.stride(0),
+                                   norm_scale.data_ptr(), x.shape[0], num_heads, _stream()), "ca_qpre_finish_f32")
 
 
 def quantize_rows_fp8(x, out=None, out_scale=None):

@@ -108,7 +108,9 @@ typedef struct {
                            /* floats (gate_stride % 4 == 0): every item of a batch has its own adaLN gates         */
   int32_t qpre_f32;        /* QKV_NORM_ROPE: 1 = q_prerope holds fp32 elements (ldp in elements, % 4 == 0): the    */
                            /* cross-attention-space vectors of modified_double_stream_block.py:189-190 without     */
-                           /* their bf16 rounding (the heat-map logits are then formed from fp32 q on both sides)  */
+                           /* their bf16 rounding (the heat-map logits are then formed from fp32 q on both sides); */
+                           /* 2 = fp32 too, but the q projection (acc + bias) BEFORE its RMS norm: the caller adds */
+                           /* a correction and normalises with ca_qpre_finish_f32                                  */
   float q_out_scale;       /* QKV_NORM_ROPE: the rotated q is multiplied by this in fp32 before its ONE rounding   */
                            /* to bf16 (0 = 1.0; k, v and q_prerope are not scaled).  With softmax_scale * log2(e)  */
                            /* here, ca_attn_fwd_bf16(scale = CA_ATTN_Q_PRESCALED) needs no per-score multiply      */
@@ -187,6 +189,11 @@ int ca_ln_modulate_f32in(const float *x, int32_t ldx, void *out, int32_t ldo, in
                          const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream);
 int ca_ln_modulate_f32in_fp8(const float *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale, int32_t M,
                              int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps, ca_stream_t stream);
+/* ca_ln_modulate_f32in with a second bf16 plane out_lo = bf16(y - float(bf16(y))) (row stride ldlo): what the bf16
+ * rounding of the modulated row y drops.  out + out_lo carry y to ~16 mantissa bits. */
+int ca_ln_modulate_f32in_split(const float *x, int32_t ldx, void *out, int32_t ldo, void *out_lo, int32_t ldlo,
+                               int32_t M, int32_t H, const ca_mod_segment *segs, int32_t n_segs, float eps,
+                               ca_stream_t stream);
 /* Same, with the result quantised for ca_gemm_fp8: out8 = e4m3 bytes (row stride ldo bytes, % 16),
  * out_scale[row] = absmax(row) / 448 (fp32 [M]). */
 int ca_ln_modulate_fp8(const void *x, int32_t ldx, void *out8, int32_t ldo, float *out_scale, int32_t M,
@@ -223,6 +230,14 @@ int ca_qknorm_rope_bf16(void *qkv, int32_t ld, int32_t M, int32_t num_heads,
 int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void *W, const void *bias, float *out,
                  int32_t ldo, int32_t N, int32_t K, int32_t silu_input, int32_t accumulate,
                  ca_stream_t stream);
+
+/* Cross-attention-space query vectors (post-QKNorm, pre-RoPE q; modified_double_stream_block.py:189-190) from the
+ * UNROUNDED LayerNorm output: x fp32 [M, heads*128] = the q projection of bf16(y) before its norm (ca_gemm_problem
+ * qpre_f32 = 2), d fp32 (or NULL) = the same weights applied to the low plane of ca_ln_modulate_f32in_split;
+ * in place  x <- RMSNorm_128(x + d) * norm_scale  per head (flux/modules/layers.py:63-72).  The rounding of the
+ * GEMM operand is ~90 % of the cross-space heat-map error of a bf16 MFMA path. */
+int ca_qpre_finish_f32(float *x, int32_t ldx, const float *d, int32_t ldd, const void *norm_scale, int32_t M,
+                       int32_t heads, ca_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Concept heat maps, one (timestep, layer) at a time (compute_heatmaps_from_vectors,

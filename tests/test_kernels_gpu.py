@@ -375,6 +375,48 @@ def test_attention_prescaled_q_two_segments_two_problems(C, T, Limg):
         ops.attention([con], nh, scale=0.1, q_prescaled=True)
 
 
+def test_split_q_capture_chain_matches_fp32_projection():
+    """The cross-attention-space q vectors from the UNROUNDED LayerNorm output: LayerNorm with its low plane
+    (ca_ln_modulate_f32in_split), the qkv projection storing q before its norm (qpre_f32 = 2), the q weights applied
+    to the low plane, ca_qpre_finish_f32.  Against fp32 rmsnorm(y32 @ Wq^T + b): an order of magnitude closer than the
+    one-rounding path, on full rows tiles and on a thin last row tile (M = 300)."""
+    from oracle import flux_oracle as O
+    nh, M, H = 2, 300, 256
+    x = torch.randn(M, H, device=DEV) * 1.5
+    sh, sc = torch.randn(H, device=DEV) * 0.2, torch.randn(H, device=DEV) * 0.3
+    w, b = rnd(3 * H, H, scale=0.08), rnd(3 * H)
+    nq, nk = (0.5 + torch.rand(128)).bfloat16().to(DEV), (0.5 + torch.rand(128)).bfloat16().to(DEV)
+    table = torch.zeros(M, 64, 2, device=DEV)
+    table[..., 0] = 1.0                                             # identity RoPE
+    hi = torch.zeros(M, H, device=DEV, dtype=torch.bfloat16)
+    lo = torch.zeros_like(hi)
+    ops.ln_modulate(x, hi, [(M, sh, sc)], out_lo=lo)
+    y32 = (1 + sc) * torch.nn.functional.layer_norm(x, (H,), eps=1e-6) + sh
+    only = torch.zeros_like(hi)
+    ops.ln_modulate(x, only, [(M, sh, sc)])
+    assert torch.equal(only, hi)                                    # the high plane is the ordinary output
+    assert (hi.float() + lo.float() - y32).abs().max() < 3e-5 * 4   # ~16 mantissa bits (|y| < ~8)
+    out = torch.zeros(M, 3 * H, device=DEV, dtype=torch.bfloat16)
+    qraw = torch.zeros(M, H, device=DEV)
+    ops.gemm([ops.Gemm(hi, w, b, out, L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=nq, norm_k=nk, rope=table,
+                       q_prerope=qraw, qpre_raw=True)])
+    out1 = torch.zeros_like(out)
+    q1 = torch.zeros(M, H, device=DEV)
+    ops.gemm([ops.Gemm(hi, w, b, out1, L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=nq, norm_k=nk, rope=table,
+                       q_prerope=q1)])
+    assert torch.equal(out, out1)                                   # the attention's q, k, v do not change
+    d = torch.zeros(M, H, device=DEV)
+    ops.gemm([ops.Gemm(lo, w[:H], None, d)])
+    plain = qraw.clone()
+    ops.qpre_finish(plain, None, nq, nh)
+    assert (plain - q1).abs().max() < 2e-5                          # without the correction: the fused epilogue's values
+    ops.qpre_finish(qraw, d, nq, nh)
+    ref = O.rms_norm((y32.cpu() @ w[:H].float().cpu().t() + b[:H].float().cpu()).view(M, nh, 128),
+                     nq.float().cpu()).reshape(M, H)
+    e_split, e_one = (qraw.cpu() - ref).abs().max().item(), (q1.cpu() - ref).abs().max().item()
+    assert e_split < 2e-4 and e_split < 0.15 * e_one, (e_split, e_one)
+
+
 def test_heatmap_logits_fp32_image_vectors():
     """fp32 image AND concept vectors (the fp32 q_prerope store): the same k order as the bf16-image form."""
     Lp, dim, C = 300, 3072, 6

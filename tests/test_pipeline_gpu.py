@@ -29,9 +29,11 @@ def test_generate_image_api_and_fused_equals_stacked(pipe):
     assert a.concept_heatmaps.shape == (3, 16, 16) and a.cross_attention_maps.shape == (3, 16, 16)
     assert a.image.shape == (16, 32, 32)  # no autoencoder injected: the unpacked latent
     assert np.abs(a.concept_heatmaps.sum(0) - 1).max() < 1e-5
-    # same kernels, same order of operations except the concept rows' fp32 copy in the fused path
+    # same kernels, same order of operations except what the fused path keeps in fp32 and the stacked dict carries in
+    # the activations' dtype (bf16, as the reference's dict): the concept rows' attention output (output space) and
+    # the pre-RoPE q vectors of both sides (cross space)
     assert np.abs(a.concept_heatmaps - b.concept_heatmaps).max() < 2e-3
-    assert np.abs(a.cross_attention_maps - b.cross_attention_maps).max() < 1e-6
+    assert np.abs(a.cross_attention_maps - b.cross_attention_maps).max() < 2e-3
     assert np.array_equal(a.image, b.image)
     c = pipe.generate_image(**{**kw, "return_pil_heatmaps": True})
     assert len(c.concept_heatmaps) == 3 and c.concept_heatmaps[0].size == (16, 16)
