@@ -24,26 +24,13 @@
 #include <atomic>
 
 #include "ca_common.h"
+#include "ca_attn_common.h"
 #ifndef CA_ATTN_KPF
 #define CA_ATTN_KPF 4
 #endif
 
 namespace {
-
-struct AttnLaunch {
-  ca_attn_problem p[CA_ATTN_MAX_PROBLEMS];
-  int32_t nqb[CA_ATTN_MAX_PROBLEMS];      // 256-row query blocks per head
-  int32_t blk_end[CA_ATTN_MAX_PROBLEMS];  // workgroups of problems 0..i (problems are laid out one after another)
-  int32_t n_problems;
-  int32_t num_heads;
-  float scale_log2;   // softmax scale * log2(e)
-};
-
-constexpr int KV_TILE = 64;
-constexpr float REDO_LIMIT = 1073741824.0f;  // 2^30: a row sum above this sends the tile through the max-tracking path
-constexpr int TILE_BYTES = KV_TILE * 256;  // one K or V tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;
-constexpr int ATTN_LDS = 2 * BUF_BYTES;
+using namespace ca_attn_detail;
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16 &s, int base) {
   bf16x8 r;

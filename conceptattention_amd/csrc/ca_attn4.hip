@@ -1,0 +1,343 @@
+// The one-wave-per-SIMD attention kernel (own translation unit: it owns the AGPR file by hand, and is compiled with
+// -mllvm -amdgpu-spill-vgpr-to-agpr=0 so that hipcc can never park a VGPR in one of those registers; build.py also
+// checks the emitted code for compiler-written AGPR accesses).
+#include <stdlib.h>
+
+#include <atomic>
+
+#include "ca_attn_common.h"
+
+namespace {
+using namespace ca_attn_detail;
+
+// =================================================================================================================
+// ca_attn4_kernel: the same attention for pre-scaled q (CA_ATTN_Q_PRESCALED) as ONE wave per SIMD.
+//
+// 4 waves x 64 query rows per workgroup (two 32-row query blocks per wave), the whole 512-entry register file per
+// wave: O^T of both query blocks (128), the Q fragments (64) and 8-fragment rings for the K and V operands live in
+// hand-owned AGPRs, the scores / probabilities, -reference and the packed P fragments in compiler-allocated VGPRs
+// (an MFMA's C and D share a register class, A and B are free; v_exp_f32 cannot read AGPRs).  Every hot
+// instruction is its own `asm volatile` statement: hipcc keeps volatile asm statements in program order, so the
+// stream below IS the schedule -- a tile is 64 MFMAs with the LDS reads, the exponentials, the row-sum adds and the
+// bf16 packs placed in the gaps between them by tools/gen_attn4_schedule.py (ca_attn4_sched.inc):
+//     slots  0..31  S(t+1) = K(t+1) Q^T   beside  the first half of softmax(t+1), the V(t) reads, the K(t+1/t+2) reads
+//     slots 32..63  O^T += V(t)^T P(t)^T  beside  the second half of softmax(t+1) and the packs of P(t+1)
+// K/V tiles arrive by LDS-DMA into 3-slot rings (K three tiles ahead: its first fragments are read one tile before
+// their MFMAs; V one tile ahead), one barrier per tile.  The softmax reference of a row is the maximum of tile 0 and
+// is kept (see ca_attn_kernel); there is no per-tile check: a row sum that left the safe range shows in the final
+// sums, and the workgroup then recomputes its rows the classical way (running maximum, rescale per tile).
+// The two waves of a SIMD in ca_attn_kernel run in lockstep (same program, one barrier per tile): per tile the matrix
+// pipe idles while both exponentiate.  Here the single wave's own stream keeps it fed.
+#define CA_A4_HELPERS
+#include "ca_attn4_sched.inc"
+#undef CA_A4_HELPERS
+
+namespace a4 {
+constexpr int SLOTS = 3;
+constexpr int V_BASE = SLOTS * TILE_BYTES;                 // V ring behind the K ring
+constexpr int LDS_BYTES = 2 * SLOTS * TILE_BYTES + 64;     // + the "recompute" flag (launch size: ca_attn_fwd_bf16)
+constexpr float L_LIMIT = 1152921504606846976.0f;          // 2^60
+}  // namespace a4
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int bid = blockIdx.x;
+  int prob = 0;
+  while (prob + 1 < L.n_problems && bid >= L.blk_end[prob]) ++prob;
+  if (prob) bid -= L.blk_end[prob - 1];
+  const int nqb = L.nqb[prob];
+  const int xg = bid & 7, idx = bid >> 3;
+  const int head = xg + 8 * (idx / nqb);
+  const int qb_wg = idx % nqb;
+  if (head >= L.num_heads) return;
+  // the descriptor's fields as scalars (indexing the by-value argument inside the loop would make hipcc keep a scratch
+  // copy of it, and scalar loads inside the tile loop would share the LDS reads' counter)
+  const ca_attn_problem &P = L.p[prob];
+  const int nq = P.nq, n0 = P.n0, nkeys = P.n0 + P.n1, nq0 = P.nq0;
+  const int ldkv = P.ldkv, ldq = P.ldq, ldo = P.ldo, ldo32 = P.ldo32;
+  const bf16 *q_a = (const bf16 *)P.q, *q_b = (const bf16 *)P.q1;
+  bf16 *o_a = (bf16 *)P.out, *o_b = (bf16 *)P.out1;
+  float *o32 = P.out_f32;
+
+  const int h = lane >> 5, ql = lane & 31;
+  const int qrow0 = qb_wg * 256 + wave * 64;
+  const bool active = qrow0 < nq;  // wave-uniform
+
+  asm volatile("" ::: CA_A4_AGPR_CLOBBERS);   // the AGPR file is ours: makes the kernel descriptor allocate it
+
+  // ---- Q fragments of both query blocks -> AGPRs
+  {
+    uint32_t qw[2][8][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int qrow = min(qrow0 + 32 * b + ql, nq - 1);
+      const bf16 *qp = (qrow < nq0 ? q_a + (size_t)qrow * ldq : q_b + (size_t)(qrow - nq0) * ldq) + head * 128 + h * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const uint4 v = *(const uint4 *)(qp + ks * 16);
+        qw[b][ks][0] = v.x, qw[b][ks][1] = v.y, qw[b][ks][2] = v.z, qw[b][ks][3] = v.w;
+      }
+    }
+    CA_A4_WRITE_Q(qw);
+  }
+  CA_A4_ZERO_O();
+
+  // ---- staging (LDS-DMA), 4 pieces of 1 KiB per wave and matrix; same images and source swizzles as ca_attn_kernel
+  const int st_row = lane >> 4, st_cp = lane & 15;
+  const bf16 *k0p = (const bf16 *)P.k0 + head * 128, *v0p = (const bf16 *)P.v0 + head * 128;
+  const bf16 *k1p = (const bf16 *)P.k1 + head * 128, *v1p = (const bf16 *)P.v1 + head * 128;
+  uint32_t koff[4], voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 4 * (wave * 4 + j) + st_row;
+    koff[j] = ((uint32_t)r * (uint32_t)ldkv + ((st_cp ^ (r & 15)) << 3)) * 2u;
+    voff[j] = ((uint32_t)r * (uint32_t)ldkv + ((st_cp ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 3)) * 2u;
+  }
+  auto stage = [&](int tile, int slot, bool is_v) {
+    char *dst = smem + (is_v ? a4::V_BASE : 0) + slot * TILE_BYTES;
+    const bf16 *p0 = is_v ? v0p : k0p, *p1 = is_v ? v1p : k1p;
+    const int lo = tile * KV_TILE;
+    const bool in0 = lo + KV_TILE <= n0, in1 = lo >= n0 && lo + KV_TILE <= nkeys;
+    if (in0 || in1) {
+      const bf16 *base = (in0 ? p0 : p1) + (size_t)(in0 ? lo : lo - n0) * ldkv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ca_glds16_asm_s(base, is_v ? voff[j] : koff[j], dst + (wave * 4 + j) * 1024);
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * (wave * 4 + j) + st_row;
+      const int kk = min(lo + r, nkeys - 1);
+      const bool s0 = kk < n0;
+      const size_t ro = (size_t)(s0 ? kk : kk - n0) * ldkv;
+      const int ch = is_v ? (st_cp ^ (((r & 3) << 2) | ((r >> 2) & 3))) : (st_cp ^ (r & 15));
+      ca_glds16_asm((s0 ? p0 : p1) + ro + (ch << 3), dst + (wave * 4 + j) * 1024);
+    }
+  };
+  auto drain_and_barrier = [&]() {   // this wave's DMA has landed, its LDS reads have returned; then everyone's
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  // ---- fragment addresses (bytes): K relative to the K ring, V with the V ring's base included
+  const uint32_t k_lane = ql * 256 + (((h ^ (ql & 15)) & 15) << 4);
+  const uint32_t ka0 = k_lane, ka1 = k_lane ^ (1 << 5), ka2 = k_lane ^ (2 << 5), ka3 = k_lane ^ (3 << 5),
+                 ka4 = k_lane ^ (4 << 5), ka5 = k_lane ^ (5 << 5), ka6 = k_lane ^ (6 << 5), ka7 = k_lane ^ (7 << 5);
+  const int qq = (lane & 15) >> 2;
+  const int c_lane = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+  uint32_t v_lane[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int x = (qq << 2) | ((2 * jj + h) & 3);
+    v_lane[jj] = a4::V_BASE + (4 * h + qq) * 256 + (((c_lane ^ x) & 15) << 4) + 8 * (lane & 1);
+  }
+  const uint32_t va00 = v_lane[0], va01 = v_lane[0] ^ (1 << 6), va02 = v_lane[0] ^ (2 << 6), va03 = v_lane[0] ^ (3 << 6);
+  const uint32_t va10 = v_lane[1], va11 = v_lane[1] ^ (1 << 6), va12 = v_lane[1] ^ (2 << 6), va13 = v_lane[1] ^ (3 << 6);
+
+  f32x16 S00, S01, S10, S11, NM0, NM1;
+  i32x4 P000, P001, P010, P011, P100, P101, P110, P111;   // P[kb][qb][sk]
+  float l0 = 0.f, l1 = 0.f, m0 = -1e30f, m1 = -1e30f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) NM0[r] = NM1[r] = 0.f, S00[r] = S01[r] = S10[r] = S11[r] = 0.f;
+  P000 = P001 = P010 = P011 = P100 = P101 = P110 = P111 = i32x4{0, 0, 0, 0};
+
+  const int nt = (nkeys + KV_TILE - 1) / KV_TILE;
+  const bool ragged = (nkeys & (KV_TILE - 1)) != 0;
+  const int nt_full = ragged ? nt - 1 : nt;
+
+  // key of S[kb][*][r] in tile t: 64 t + 32 kb + (r&3) + 8 (r>>2) + 4 h
+  auto mask_tail = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = t * KV_TILE + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (key >= nkeys) S00[r] = S01[r] = -INFINITY;
+      if (key + 32 >= nkeys) S10[r] = S11[r] = -INFINITY;
+    }
+  };
+  auto pack_one = [&](i32x4 &Pf, const f32x16 &Sv, int base) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Pf[j] = (int)ca_pack2(Sv[base + 2 * j], Sv[base + 2 * j + 1]);
+  };
+  auto pack_all = [&]() {
+    pack_one(P000, S00, 0), pack_one(P001, S00, 8), pack_one(P010, S01, 0), pack_one(P011, S01, 8);
+    pack_one(P100, S10, 0), pack_one(P101, S10, 8), pack_one(P110, S11, 0), pack_one(P111, S11, 8);
+  };
+  // S holds scores minus the reference (or raw scores with *mref = the reference to subtract): P = exp2, row sums
+  auto exp_sum = [&](float sub0, float sub1) {
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S00[r] = __builtin_amdgcn_exp2f(S00[r] - sub0), S10[r] = __builtin_amdgcn_exp2f(S10[r] - sub0);
+      S01[r] = __builtin_amdgcn_exp2f(S01[r] - sub1), S11[r] = __builtin_amdgcn_exp2f(S11[r] - sub1);
+      r0 += S00[r] + S10[r];
+      r1 += S01[r] + S11[r];
+    }
+    l0 += r0;
+    l1 += r1;
+  };
+  auto row_max = [&](float &x0, float &x1) {
+    x0 = S00[0], x1 = S01[0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      x0 = fmaxf(x0, fmaxf(S00[r], S10[r]));
+      x1 = fmaxf(x1, fmaxf(S01[r], S11[r]));
+    }
+    x0 = fmaxf(x0, __shfl_xor(x0, 32));
+    x1 = fmaxf(x1, __shfl_xor(x1, 32));
+  };
+  auto set_reference = [&](float r0, float r1) {
+    m0 = r0, m1 = r1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) NM0[r] = -r0, NM1[r] = -r1;
+    asm volatile("s_nop 7" : "+v"(NM0), "+v"(NM1));   // VALU write -> MFMA C operand (the asm MFMAs are opaque to hipcc)
+  };
+
+  // ---- prologue: K(0), V(0), K(1), K(2)
+  stage(0, 0, false);
+  stage(0, 0, true);
+  if (nt > 1) stage(1, 1, false);
+  if (nt > 2) stage(2, 2, false);
+  drain_and_barrier();
+
+  // ---- tile 0 sets the reference (the only tile whose maximum is computed)
+  if (active) {
+    CA_A4_QK_PLAIN_ZERO(0u);
+    if (nt_full == 0) mask_tail(0);
+    float x0, x1;
+    row_max(x0, x1);
+    set_reference(x0, x1);
+    exp_sum(x0, x1);
+    pack_all();
+  }
+  drain_and_barrier();   // every wave is done with K(0) before iteration 0 lets the DMA overwrite its slot
+
+  // ---- pipelined tiles: iteration t = K(t+1) Q^T + softmax(t+1) beside O^T += V(t)^T P(t)^T
+  const int T = nt_full > 0 ? nt_full - 1 : 0;
+  if (T > 0 && active) CA_A4_PRELOAD_K0((uint32_t)TILE_BYTES);
+  for (int t = 0; t < T; ++t) {
+    if (t + 3 < nt) stage(t + 3, t % 3, false);
+    if (t + 1 < nt) stage(t + 1, (t + 1) % 3, true);
+    if (active) {
+      const int R = t % 3;
+#define CA_A4_SCHEDULE
+#include "ca_attn4_sched.inc"
+#undef CA_A4_SCHEDULE
+    }
+    drain_and_barrier();
+  }
+  // softmax done through tile T, P.V through tile T-1
+  if (active) {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(S00), "+v"(S01), "+v"(S10), "+v"(S11));
+    pack_one(P101, S10, 8), pack_one(P111, S11, 8);   // the packs the next iteration would have started with
+    asm volatile("s_nop 3" : "+v"(P101), "+v"(P111));
+    CA_A4_PV_PLAIN((uint32_t)((T % 3) * TILE_BYTES));
+  }
+  if (ragged && nt > 1) {   // tile nt - 1 = T + 1: its K is staged (prologue or iteration T - 2), its V is not
+    stage(T + 1, (T + 1) % 3, true);
+    drain_and_barrier();
+    if (active) {
+      CA_A4_QK_PLAIN_NEGM((uint32_t)(((T + 1) % 3) * TILE_BYTES));
+      mask_tail(T + 1);
+      exp_sum(0.f, 0.f);
+      pack_all();
+      CA_A4_PV_PLAIN((uint32_t)(((T + 1) % 3) * TILE_BYTES));
+    }
+  }
+
+  // ---- did any row leave the safe range?  (workgroup-uniform decision: the recomputation stages tiles together)
+  int *flag = (int *)(smem + 2 * a4::SLOTS * TILE_BYTES);
+  if (tid == 0) *flag = 0;
+  drain_and_barrier();
+  if (active && __builtin_amdgcn_ballot_w64(!(l0 <= a4::L_LIMIT) || !(l1 <= a4::L_LIMIT)) != 0 && lane == 0) *flag = 1;
+  drain_and_barrier();
+  if (*flag) {
+    // classical online softmax, one tile at a time, nothing overlapped (rare: a score > 60 octaves above tile 0's max)
+    CA_A4_ZERO_O();
+    l0 = l1 = 0.f;
+    m0 = m1 = -1e30f;
+    for (int t = 0; t < nt; ++t) {
+      drain_and_barrier();
+      stage(t, 0, false);
+      stage(t, 0, true);
+      drain_and_barrier();
+      if (active) {
+        CA_A4_QK_PLAIN_ZERO(0u);
+        if (ragged && t == nt - 1) mask_tail(t);
+        float x0, x1;
+        row_max(x0, x1);
+        const float n0_ = fmaxf(m0, x0), n1_ = fmaxf(m1, x1);
+        const float al0 = __builtin_amdgcn_exp2f(m0 - n0_), al1 = __builtin_amdgcn_exp2f(m1 - n1_);
+        CA_A4_SCALE_O(al0, al1);
+        l0 *= al0, l1 *= al1;
+        m0 = n0_, m1 = n1_;
+        exp_sum(m0, m1);
+        pack_all();
+        CA_A4_PV_PLAIN(0u);
+      }
+    }
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l, as ca_attn_kernel (16-byte stores via v_permlane32_swap)
+  if (active) {
+    f32x16 of[2][4];
+    CA_A4_READ_O(of);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float lr = b ? l1 : l0;
+      const float inv = 1.0f / (lr + __shfl_xor(lr, 32));
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const int row = qrow0 + 32 * b + ql;
+      const int orow = min(row, nq - 1);
+      bf16 *op = (orow < nq0 ? o_a + (size_t)orow * ldo : o_b + (size_t)(orow - nq0) * ldo) + head * 128 + 8 * h;
+      const bool row_ok = row < nq;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          const f32x16 &o = of[b][db];
+          const uint32_t ax = ca_pack2(o[4 * g] * inv, o[4 * g + 1] * inv);
+          const uint32_t ay = ca_pack2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+          const uint32_t bx = ca_pack2(o[4 * g + 4] * inv, o[4 * g + 5] * inv);
+          const uint32_t by = ca_pack2(o[4 * g + 6] * inv, o[4 * g + 7] * inv);
+          const u32x2 sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+          const u32x2 sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+          if (row_ok) *(uint4 *)(op + 32 * db + 8 * g) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      if (row_ok && o32) {
+        float *fp = o32 + (size_t)row * ldo32 + head * 128 + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x16 &o = of[b][db];
+            *(f32x4 *)(fp + 32 * db + 8 * g) =
+                f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+          }
+      }
+    }
+  }
+}
+
+
+}  // namespace
+
+int ca_attn4_launch(const AttnLaunch &L, int total, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_done{0};
+  const unsigned long long dev_bit = ca_device_bit();
+  if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
+    const hipError_t e = hipFuncSetAttribute((const void *)ca_attn4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             a4::LDS_BYTES);
+    if (e != hipSuccess) {
+      ca_set_error("ca_attn_fwd_bf16: hipFuncSetAttribute(ca_attn4_kernel): %s", hipGetErrorString(e));
+      return CA_ERR_LAUNCH;
+    }
+    attr_done.fetch_or(dev_bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(ca_attn4_kernel, dim3(total), dim3(256), a4::LDS_BYTES, stream, L);
+  return CA_OK;
+}

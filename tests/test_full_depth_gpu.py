@@ -30,12 +30,20 @@ from conceptattention_amd.weights import synthetic_inputs  # noqa: E402
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = {}
-# Absolute bounds on max-abs map error vs the fp32 oracle, set to <= 1.5 x the measured values
-# (profiles/r03_full_depth_parity.json); the first is the north star's bound on what generate_image returns.
-FINAL_OUT_BOUND = 1e-3       # measured 4.8e-4
-FINAL_CROSS_BOUND = 3e-3     # measured 1.4e-3 (round 2); tightened below once the cross-space change is measured
-SINGLE_OUT_BOUND = 5e-3
-SINGLE_CROSS_BOUND = 1e-2
+# Absolute bounds on the max-abs map error vs the fp32 oracle, each <= 1.5 x the value measured on MI355X
+# (profiles/r03_full_depth_parity.json).  The north star's bound is 1e-3 on the maps generate_image returns.
+# Cross space: with the same input as the oracle (step 0 of a generation, the encode path) a map is within 4.5e-4 -- the
+# q vectors come from the unrounded LayerNorm output (HipFluxDiT.split_q_capture); at steps >= 1 of a generation the
+# latent itself has moved (pred: 0.24-0.37 % rms off the fp32 trajectory after 57 bf16 blocks per step) and the
+# cross-space logits amplify that: 2-4e-3 per map, 1.07e-3 for the 16-map mean.
+FINAL_OUT_BOUND = 9e-4            # schnell 4 steps: 5.9e-4; dev 2 steps: 2.8e-4
+FINAL_CROSS_BOUND = 1.6e-3        # schnell 4 steps: 1.07e-3; dev 2 steps: 3.9e-4; encode: 1.6e-4
+SINGLE_OUT_BOUND = 4.0e-3         # any (step, layer): <= 2.72e-3 (step 3); step 0: <= 1.48e-3
+SINGLE_OUT_STEP0_BOUND = 2.2e-3
+SINGLE_CROSS_BOUND = 6.5e-3       # any (step, layer): <= 4.34e-3 (step 3)
+SINGLE_CROSS_SAME_INPUT_BOUND = 7.5e-4   # step 0 / encode path (the oracle's own input): <= 4.8e-4
+ENCODE_FINAL_OUT_BOUND = 1.5e-3   # one forward, mean of 4 layers: 9.6e-4
+ENCODE_FINAL_CROSS_BOUND = 2.5e-4 # 1.6e-4
 
 
 def bf_inputs(p, size, T, C):
@@ -121,13 +129,13 @@ def test_four_steps_full_depth_vs_fp32_golden_with_reference_bf16_yardstick(pipe
         assert e <= max(1e-3, yref), (space, s, l, e, yref)
     assert fo <= max(1e-3, float(y["final_err_out_fp32reduce"]))
     assert fc <= max(1e-3, float(y["final_err_cross_fp32reduce"]))
-    # ... and in absolute terms (measured with the fp32 residual stream: final output-space maps 4.8e-4, final
-    # cross-space maps 1.4e-3; single (step, layer) maps 1.2-1.7e-3 at step 0, up to 3.4e-3 / 6.4e-3 at step 3).
-    # The first line is the north star's bound: the maps generate_image returns are within 1e-3 of fp32.
-    assert fo <= 1e-3, fo
-    assert fc <= 3e-3, fc
-    assert max(v[0] for k, v in rep["out"].items() if k.startswith("step0")) <= 2.5e-3
-    assert max(v[0] for v in rep["out"].values()) <= 5e-3 and max(v[0] for v in rep["cross"].values()) <= 1e-2
+    # ... and in absolute terms (bounds and measured values at the top of this file)
+    assert fo <= FINAL_OUT_BOUND, fo
+    assert fc <= FINAL_CROSS_BOUND, fc
+    assert max(v[0] for k, v in rep["out"].items() if k.startswith("step0")) <= SINGLE_OUT_STEP0_BOUND
+    assert max(v[0] for k, v in rep["cross"].items() if k.startswith("step0")) <= SINGLE_CROSS_SAME_INPUT_BOUND
+    assert max(v[0] for v in rep["out"].values()) <= SINGLE_OUT_BOUND
+    assert max(v[0] for v in rep["cross"].values()) <= SINGLE_CROSS_BOUND
     assert rep["final_latent_rel_rms"] <= max(0.02, rep["reference_bf16_final_latent_rel_rms"])
     # the product entry point gives the same final maps as the per-layer tables (same kernels, same order)
     d = {k: v.to(DEV) for k, v in inp.items()}
@@ -224,7 +232,7 @@ def test_encode_path_full_size_vs_fp32_golden(pipe, golden):
         rep["cross"][f"layer{l}"] = [ec, float(y["err_cross"][0, l])]
         assert eo <= max(1e-3, float(y["err_out"][0, l])), (l, eo)
         assert ec <= max(1e-3, float(y["err_cross"][0, l])), (l, ec)
-        assert eo <= SINGLE_OUT_BOUND and ec <= SINGLE_CROSS_BOUND, (l, eo, ec)
+        assert eo <= SINGLE_OUT_BOUND and ec <= SINGLE_CROSS_SAME_INPUT_BOUND, (l, eo, ec)
     # the product entry point (encode_image's device core) on the same noise: the mean over layers 15..18
     ho, hc = pipe.encode_many_on_device([item], batch=1, noise=[noise])[0]
     fo = float(np.abs(ho[0].reshape(C, -1).cpu().numpy() - g["final_out"]).max())
@@ -233,8 +241,8 @@ def test_encode_path_full_size_vs_fp32_golden(pipe, golden):
     REPORT["encode_full"] = rep
     print("encode full size:", rep)
     assert np.abs(ho[0].reshape(C, -1).cpu().numpy() - out[15:19].mean(0)).max() < 1e-5
-    assert fo <= max(1e-3, float(y["final_err_out_fp32reduce"])) and fo <= FINAL_OUT_BOUND
-    assert fc <= max(1e-3, float(y["final_err_cross_fp32reduce"])) and fc <= FINAL_CROSS_BOUND
+    assert fo <= max(1e-3, float(y["final_err_out_fp32reduce"])) and fo <= ENCODE_FINAL_OUT_BOUND
+    assert fc <= max(1e-3, float(y["final_err_cross_fp32reduce"])) and fc <= ENCODE_FINAL_CROSS_BOUND
 
 
 @pytest.fixture(scope="module")
@@ -273,7 +281,8 @@ def test_flux_dev_two_steps_full_depth_vs_fp32_golden(dev_pipe, golden):
         rep["cross"][f"step{s}_layer{l}"] = [ec, float(y["err_cross"][s, l])]
         assert eo <= max(1e-3, float(y["err_out"][s, l])), (s, l, eo, float(y["err_out"][s, l]))
         assert ec <= max(1e-3, float(y["err_cross"][s, l])), (s, l, ec, float(y["err_cross"][s, l]))
-        assert eo <= SINGLE_OUT_BOUND and ec <= SINGLE_CROSS_BOUND, (s, l, eo, ec)
+        assert eo <= SINGLE_OUT_STEP0_BOUND and ec <= (SINGLE_CROSS_SAME_INPUT_BOUND if s == 0 else SINGLE_CROSS_BOUND), \
+            (s, l, eo, ec)
         agree = float((cross[s, l].argmax(0) == gc.argmax(0)).mean())
         assert agree >= min(0.985, float(y["agree_cross"][s, l])), (s, l, agree)
     fo = float(np.abs(out[:, 15:19].mean((0, 1)) - g["final_out"]).max())

@@ -178,7 +178,7 @@ def test_pipeline_attention_norm_branches():
         a = pipe.generate_image(softmax=False, attention_norm=norm, **kw)
         b = pipe.generate_image(softmax=False, attention_norm=norm, fused=False, **kw)
         assert np.abs(a.concept_heatmaps.sum(0) - 1).max() < 1e-5
-        assert np.abs(a.cross_attention_maps - b.cross_attention_maps).max() < 1e-6
+        assert np.abs(a.cross_attention_maps - b.cross_attention_maps).max() < 5e-3   # fp32 vs bf16 q vectors
         assert np.abs(a.concept_heatmaps - b.concept_heatmaps).max() < 5e-3  # fp32 vs bf16 concept rows
         assert not np.array_equal(a.concept_heatmaps, soft.concept_heatmaps)
     with pytest.raises(ValueError):
