@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libconceptattn.so")
+# CA_LIB_PATH: another build of the same library (A/B and diagnostic builds under tools/ab_libs); still no fallback
+LIB_PATH = os.environ.get("CA_LIB_PATH") or os.path.join(_HERE, "libconceptattn.so")
 
 CA_VERSION = 120
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU, EPI_QKV_NORM_ROPE = 0, 1, 2, 3, 4

@@ -380,7 +380,11 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   // Default: 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: ~250 us for
   // 4352x4352x24 heads on MI355X.  A/B aid (same numerics): CA_ATTN_WAVES=4 = 128-row workgroups.
   static const int nw = (getenv("CA_ATTN_WAVES") && atoi(getenv("CA_ATTN_WAVES")) == 4) ? 4 : 8;
-  const int qrows = nw * 32;
+  // pre-scaled q: CA_ATTN_KERNEL=4 selects the one-wave-per-SIMD kernel (ca_attn4.hip; 4 waves x 64 rows = 256 rows per
+  // workgroup as well, same numerics contract); default: the two-waves-per-SIMD kernel below
+  static const bool want4 = getenv("CA_ATTN_KERNEL") && atoi(getenv("CA_ATTN_KERNEL")) == 4;
+  const bool use4 = pre && want4;
+  const int qrows = use4 ? 256 : nw * 32;
   AttnLaunch L = {};
   L.num_heads = num_heads;
   L.n_problems = n_problems;
@@ -424,6 +428,16 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
     L.nqb[i] = (p.nq + qrows - 1) / qrows;
     total += 8 * hx * L.nqb[i];
     L.blk_end[i] = total;
+  }
+  if (use4) {
+    const int rc = ca_attn4_launch(L, total, (hipStream_t)stream);
+    if (rc != CA_OK) return rc;
+    const hipError_t e4 = hipGetLastError();
+    if (e4 != hipSuccess) {
+      ca_set_error("ca_attn_fwd_bf16: launch failed: %s", hipGetErrorString(e4));
+      return CA_ERR_LAUNCH;
+    }
+    return CA_OK;
   }
   static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
   const unsigned long long dev_bit = ca_device_bit();

@@ -35,11 +35,21 @@ using namespace ca_attn_detail;
 namespace a4 {
 constexpr int SLOTS = 3;
 constexpr int V_BASE = SLOTS * TILE_BYTES;                 // V ring behind the K ring
-constexpr int LDS_BYTES = 2 * SLOTS * TILE_BYTES + 64;     // + the "recompute" flag (launch size: ca_attn_fwd_bf16)
+constexpr int FLAG_OFF = 2 * SLOTS * TILE_BYTES;           // the "recompute" flag
+constexpr int DUMP_OFF = FLAG_OFF + 1024;                  // 16 KiB nobody reads: where the tile loop's LDS-DMA pieces land
+                                                           // when there is no tile for them (they then re-read a valid one)
+constexpr int LDS_BYTES = DUMP_OFF + TILE_BYTES;
 constexpr float L_LIMIT = 1152921504606846976.0f;          // 2^60
 }  // namespace a4
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef CA_A4_STAMP   // diagnostic build only (tools/stamp_attn4.py): cycles per loop segment, per workgroup and wave
+__device__ unsigned long long ca_a4_dbg[4 * 4 * 4096];
+#define CA_A4_T(x) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); } while (0)
+#else
+#define CA_A4_T(x) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
@@ -64,6 +74,10 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
   const bf16 *q_a = (const bf16 *)P.q, *q_b = (const bf16 *)P.q1;
   bf16 *o_a = (bf16 *)P.out, *o_b = (bf16 *)P.out1;
   float *o32 = P.out_f32;
+
+  const int nt = (nkeys + KV_TILE - 1) / KV_TILE;
+  const bool ragged = (nkeys & (KV_TILE - 1)) != 0;
+  const int nt_full = ragged ? nt - 1 : nt;
 
   const int h = lane >> 5, ql = lane & 31;
   const int qrow0 = qb_wg * 256 + wave * 64;
@@ -120,6 +134,64 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
       ca_glds16_asm((s0 ? p0 : p1) + ro + (ch << 3), dst + (wave * 4 + j) * 1024);
     }
   };
+  // The tile loop issues its LDS-DMA from inside the instruction stream (one piece per MFMA gap, scalar tile base + the
+  // lane offsets koff / voff, no branch): tile bases and LDS destinations of the next K / V tile for that form.  A tile
+  // that straddles the two key segments or is ragged is staged here, the general way; for it, and for a tile past the
+  // end, the stream's pieces re-read a tile that is known to be addressable (SAFE: the first of tiles 0 and 1 that lies
+  // inside one segment -- the loop only runs when both are full tiles, and a segment boundary cuts at most one of them)
+  // into the dump page.  Everything here is wave-uniform scalar arithmetic (about a dozen SALU instructions per tile).
+  uint64_t DMAK = 0, DMAV = 0;
+  uint32_t LDK = 0, LDV = 0;
+  const uint32_t koff0 = koff[0], koff1 = koff[1], koff2 = koff[2], koff3 = koff[3];
+  const uint32_t voff0 = voff[0], voff1 = voff[1], voff2 = voff[2], voff3 = voff[3];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(ca_lptr)smem;
+  const uint32_t dump_dst = lds0 + a4::DUMP_OFF + wave * 4096;
+  auto uni64 = [&](const void *p) {
+    const uint64_t b = (uint64_t)(uintptr_t)p;
+    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)b);
+  };
+  const uint64_t kb0 = uni64(k0p), kb1 = uni64(k1p), vb0 = uni64(v0p), vb1 = uni64(v1p);
+  const uint64_t row_bytes = (uint64_t)(uint32_t)ldkv * 2u;
+  auto tile_base = [&](int tile, bool is_v, bool &fast) -> uint64_t {   // base of a tile that lies inside one segment
+    const int lo = tile * KV_TILE;
+    const bool in0 = lo + KV_TILE <= n0, in1 = lo >= n0 && lo + KV_TILE <= nkeys;
+    fast = in0 || in1;
+    return (in0 ? (is_v ? vb0 : kb0) : (is_v ? vb1 : kb1)) + (uint64_t)(uint32_t)(in0 ? lo : lo - n0) * row_bytes;
+  };
+  uint64_t safe_k = kb0, safe_v = vb0;
+  {
+    bool f0;
+    const uint64_t k_t0 = tile_base(0, false, f0), v_t0 = tile_base(0, true, f0);
+    bool f1;
+    const uint64_t k_t1 = tile_base(1, false, f1), v_t1 = tile_base(1, true, f1);
+    safe_k = f0 ? k_t0 : k_t1, safe_v = f0 ? v_t0 : v_t1;   // (only used when the loop runs: then f0 || f1)
+  }
+  auto dma_prepare = [&](int tile, int slot, bool is_v) {
+    bool fast;
+    const uint64_t b = tile_base(tile, is_v, fast);
+    fast = fast && tile < nt;
+    if (tile < nt && !fast) stage(tile, slot, is_v);
+#ifdef CA_A4_SKIP_DMA   // bisecting aid (with CA_A4_GEN_SKIP=1 in the generator): base 0 = the stream skips the pieces
+    const uint64_t base = fast ? b : 0;
+#else
+    const uint64_t base = fast ? b : (is_v ? safe_v : safe_k);
+#endif
+    const uint32_t dst = fast ? lds0 + (is_v ? a4::V_BASE : 0) + slot * TILE_BYTES + wave * 4096 : dump_dst;
+    if (is_v) DMAV = base, LDV = dst;
+    else DMAK = base, LDK = dst;
+  };
+  auto stage_pieces = [&]() {   // the same 8 pieces from a wave that computes nothing (its query rows do not exist)
+    auto piece = [&](uint64_t base, uint32_t off, uint32_t dst) {
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (DMAK) piece(DMAK, koff[j], LDK + 1024 * j);
+      if (DMAV) piece(DMAV, voff[j], LDV + 1024 * j);
+    }
+  };
   auto drain_and_barrier = [&]() {   // this wave's DMA has landed, its LDS reads have returned; then everyone's
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
@@ -141,14 +213,11 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
 
   f32x16 S00, S01, S10, S11, NM0, NM1;
   i32x4 P000, P001, P010, P011, P100, P101, P110, P111;   // P[kb][qb][sk]
-  float l0 = 0.f, l1 = 0.f, m0 = -1e30f, m1 = -1e30f;
+  float l0 = 0.f, l1 = 0.f, l0b = 0.f, l1b = 0.f, m0 = -1e30f, m1 = -1e30f;   // row sum of block b = lb + lbb
 #pragma unroll
   for (int r = 0; r < 16; ++r) NM0[r] = NM1[r] = 0.f, S00[r] = S01[r] = S10[r] = S11[r] = 0.f;
   P000 = P001 = P010 = P011 = P100 = P101 = P110 = P111 = i32x4{0, 0, 0, 0};
 
-  const int nt = (nkeys + KV_TILE - 1) / KV_TILE;
-  const bool ragged = (nkeys & (KV_TILE - 1)) != 0;
-  const int nt_full = ragged ? nt - 1 : nt;
 
   // key of S[kb][*][r] in tile t: 64 t + 32 kb + (r&3) + 8 (r>>2) + 4 h
   auto mask_tail = [&](int t) {
@@ -211,30 +280,113 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
     float x0, x1;
     row_max(x0, x1);
     set_reference(x0, x1);
-    exp_sum(x0, x1);
-    pack_all();
+    // ... and leaves the tile in the state every iteration of the loop below starts from (the loop's softmax runs one
+    // exponential per MFMA gap and laps into the next iteration, ca_attn4_sched.inc): everything exponentiated, summed
+    // and packed EXCEPT  S11[6..15] still raw (score - reference),  S11[4], S11[5] not yet in the row sum,
+    // P101 / P110 / P111 not packed.  finish_pending() completes that state behind the loop.
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S00[r] = __builtin_amdgcn_exp2f(S00[r] - x0), S10[r] = __builtin_amdgcn_exp2f(S10[r] - x0);
+      S01[r] = __builtin_amdgcn_exp2f(S01[r] - x1);
+      r0 += S00[r] + S10[r];
+      r1 += S01[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < 6) S11[r] = __builtin_amdgcn_exp2f(S11[r] - x1);
+      else S11[r] = S11[r] - x1;
+      if (r < 4) r1 += S11[r];
+    }
+    l0 += r0, l1 += r1;
+    pack_one(P000, S00, 0), pack_one(P001, S00, 8), pack_one(P010, S01, 0), pack_one(P011, S01, 8);
+    pack_one(P100, S10, 0);
   }
   drain_and_barrier();   // every wave is done with K(0) before iteration 0 lets the DMA overwrite its slot
 
-  // ---- pipelined tiles: iteration t = K(t+1) Q^T + softmax(t+1) beside O^T += V(t)^T P(t)^T
+  // ---- pipelined tiles: iteration t = K(t+1) Q^T + softmax(t+1) beside O^T += V(t)^T P(t)^T.  The ring slots of an
+  // iteration are instruction immediates (t % 3), so the loop body is three iterations in a row.
   const int T = nt_full > 0 ? nt_full - 1 : 0;
   if (T > 0 && active) CA_A4_PRELOAD_K0((uint32_t)TILE_BYTES);
-  for (int t = 0; t < T; ++t) {
-    if (t + 3 < nt) stage(t + 3, t % 3, false);
-    if (t + 1 < nt) stage(t + 1, (t + 1) % 3, true);
-    if (active) {
-      const int R = t % 3;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, acc0 = 0, acc1 = 0, acc2 = 0;
+  (void)ts0, (void)ts1, (void)ts2, (void)ts3, (void)acc0, (void)acc1, (void)acc2;
+#ifdef CA_A4_STAMP
+#define CA_A4_ACC() do { acc0 += ts1 - ts0; acc1 += ts2 - ts1; acc2 += ts3 - ts2; } while (0)
+#else
+#define CA_A4_ACC() do { } while (0)
+#endif
+  int t = 0;
+  while (t + 3 <= T) {
+    { constexpr int R = 0; CA_A4_T(ts0); dma_prepare(t + 3, 0, false); dma_prepare(t + 1, 1, true); CA_A4_T(ts1);
+      if (active) {
 #define CA_A4_SCHEDULE
 #include "ca_attn4_sched.inc"
 #undef CA_A4_SCHEDULE
-    }
-    drain_and_barrier();
+      } else {
+        stage_pieces();
+      }
+      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
+    { constexpr int R = 1; CA_A4_T(ts0); dma_prepare(t + 3, 1, false); dma_prepare(t + 1, 2, true); CA_A4_T(ts1);
+      if (active) {
+#define CA_A4_SCHEDULE
+#include "ca_attn4_sched.inc"
+#undef CA_A4_SCHEDULE
+      } else {
+        stage_pieces();
+      }
+      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
+    { constexpr int R = 2; CA_A4_T(ts0); dma_prepare(t + 3, 2, false); dma_prepare(t + 1, 0, true); CA_A4_T(ts1);
+      if (active) {
+#define CA_A4_SCHEDULE
+#include "ca_attn4_sched.inc"
+#undef CA_A4_SCHEDULE
+      } else {
+        stage_pieces();
+      }
+      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
   }
+  if (t < T) {   // (t % 3 == 0 here) one or two iterations left
+    { constexpr int R = 0; CA_A4_T(ts0); dma_prepare(t + 3, 0, false); dma_prepare(t + 1, 1, true); CA_A4_T(ts1);
+      if (active) {
+#define CA_A4_SCHEDULE
+#include "ca_attn4_sched.inc"
+#undef CA_A4_SCHEDULE
+      } else {
+        stage_pieces();
+      }
+      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
+    if (t < T) {
+      constexpr int R = 1; CA_A4_T(ts0); dma_prepare(t + 3, 1, false); dma_prepare(t + 1, 2, true); CA_A4_T(ts1);
+      if (active) {
+#define CA_A4_SCHEDULE
+#include "ca_attn4_sched.inc"
+#undef CA_A4_SCHEDULE
+      } else {
+        stage_pieces();
+      }
+      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
+  }
+#ifdef CA_A4_STAMP
+  if (lane == 0 && blockIdx.x < 4096) {
+    unsigned long long *d = ca_a4_dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+    d[0] = acc0, d[1] = acc1, d[2] = acc2, d[3] = (unsigned long long)T;
+  }
+#endif
   // softmax done through tile T, P.V through tile T-1
   if (active) {
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(S00), "+v"(S01), "+v"(S10), "+v"(S11));
-    pack_one(P101, S10, 8), pack_one(P111, S11, 8);   // the packs the next iteration would have started with
-    asm volatile("s_nop 3" : "+v"(P101), "+v"(P111));
+    // finish_pending: what the next iteration would have done in its first gaps (see the first tile above)
+    {
+      float r1 = S11[4] + S11[5];
+#pragma unroll
+      for (int r = 6; r < 16; ++r) {
+        S11[r] = __builtin_amdgcn_exp2f(S11[r]);
+        r1 += S11[r];
+      }
+      l1 += r1;
+      pack_one(P101, S10, 8), pack_one(P110, S11, 0), pack_one(P111, S11, 8);
+    }
+    asm volatile("s_nop 3" : "+v"(P101), "+v"(P110), "+v"(P111));
     CA_A4_PV_PLAIN((uint32_t)((T % 3) * TILE_BYTES));
   }
   if (ragged && nt > 1) {   // tile nt - 1 = T + 1: its K is staged (prologue or iteration T - 2), its V is not
@@ -250,9 +402,11 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
   }
 
   // ---- did any row leave the safe range?  (workgroup-uniform decision: the recomputation stages tiles together)
-  int *flag = (int *)(smem + 2 * a4::SLOTS * TILE_BYTES);
+  int *flag = (int *)(smem + a4::FLAG_OFF);
   if (tid == 0) *flag = 0;
   drain_and_barrier();
+  l0 += l0b, l1 += l1b;
+  l0b = l1b = 0.f;
   if (active && __builtin_amdgcn_ballot_w64(!(l0 <= a4::L_LIMIT) || !(l1 <= a4::L_LIMIT)) != 0 && lane == 0) *flag = 1;
   drain_and_barrier();
   if (*flag) {
@@ -284,10 +438,10 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l, as ca_attn_kernel (16-byte stores via v_permlane32_swap)
   if (active) {
-    f32x16 of[2][4];
-    CA_A4_READ_O(of);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
+      f32x16 of1[4];   // one query block at a time: 64 registers
+      if (b == 0) CA_A4_READ_O0(of1); else CA_A4_READ_O1(of1);
       const float lr = b ? l1 : l0;
       const float inv = 1.0f / (lr + __shfl_xor(lr, 32));
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -299,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
-          const f32x16 &o = of[b][db];
+          const f32x16 &o = of1[db];
           const uint32_t ax = ca_pack2(o[4 * g] * inv, o[4 * g + 1] * inv);
           const uint32_t ay = ca_pack2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
           const uint32_t bx = ca_pack2(o[4 * g + 4] * inv, o[4 * g + 5] * inv);
@@ -314,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
         for (int db = 0; db < 4; ++db)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x16 &o = of[b][db];
+            const f32x16 &o = of1[db];
             *(f32x4 *)(fp + 32 * db + 8 * g) =
                 f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
           }
@@ -325,6 +479,12 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
 
 
 }  // namespace
+
+#ifdef CA_A4_STAMP
+extern "C" int ca_debug_read_attn4(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_a4_dbg), sizeof(unsigned long long) * 4 * 4 * 4096);
+}
+#endif
 
 int ca_attn4_launch(const AttnLaunch &L, int total, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};

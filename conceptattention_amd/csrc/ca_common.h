@@ -50,10 +50,14 @@ __device__ __forceinline__ void ca_glds16_asm_s(const void *sbase_uniform, uint3
   const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
   const uint64_t base = ((uint64_t)bhi << 32) | blo;
   uint32_t keep;
+  // s_nop 4: the base pair comes straight from v_readfirstlane / scalar arithmetic, and an SGPR written by VALU or
+  // SALU needs 5 wait states before a VMEM instruction may use it as its address (hipcc pads nothing inside an asm
+  // statement; with s_nop 0 here the copy intermittently read from a stale base: a memory fault that came and went
+  // with the launch timing).  It also covers the one state between the M0 write and the LDS-DMA.
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
+      "s_nop 4\n\t"
       "global_load_lds_dwordx4 %1, %2\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)

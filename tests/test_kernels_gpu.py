@@ -342,7 +342,7 @@ def test_attention_kept_reference_band_spikes(alpha, where):
         assert (out[17].float() - vv[int(s17.argmax())].float()).abs().max() < 5e-2
 
 
-@pytest.mark.parametrize("C,T,Limg", [(5, 40, 333), (4, 64, 256), (1, 7, 70)])
+@pytest.mark.parametrize("C,T,Limg", [(5, 40, 333), (4, 64, 256), (1, 7, 70), (3, 8, 256), (8, 512, 1024)])
 def test_attention_prescaled_q_two_segments_two_problems(C, T, Limg):
     """CA_ATTN_Q_PRESCALED: q rows that already carry softmax_scale * log2(e) (written so by the qkv epilogue); the
     kernel's probability is a bare exp2 and every tile's K Q^T chain starts from -reference.  Same result as the

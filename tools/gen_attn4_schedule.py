@@ -70,10 +70,12 @@ class Stream:
         text = []
         for tpl, ops in self.cur:
             text.append(tpl.format(*[f"%{num[e]}" for e, _ in ops]))
-        o = ", ".join(f'"{"+v" if "r" in mode[e] else "=&v"}"({e})' for e in outs)
-        i = ", ".join(f'"v"({e})' for e in inps)
+        cls = lambda e: "s" if "s" in mode[e] else "v"     # mode letter 's': a scalar (SGPR) operand
+        o = ", ".join(f'"{"+" if "r" in mode[e] else "=&"}{cls(e)}"({e})' for e in outs)
+        i = ", ".join(f'"{cls(e)}"({e})' for e in inps)
         body = "\\n\\t".join(text)
-        self.lines.append(f'    asm volatile("{body}" : {o} : {i} : "memory");')
+        clob = '"memory", "scc"' if any(t.startswith(("s_cmp", "s_add")) for t in text) else '"memory"'
+        self.lines.append(f'    asm volatile("{body}" : {o} : {i} : {clob});')
         self.cur = []
 
     def comment(self, c):
@@ -93,7 +95,8 @@ class Stream:
         self.tag[name] = self.lds
 
     def wait_for(self, name):
-        self.ins(f"s_waitcnt lgkmcnt({self.lds - self.tag[name]})")
+        assert name in self.tag, f"{name} waited for before it was issued"
+        self.ins(f"s_waitcnt lgkmcnt({min(self.lds - self.tag[name], 15)})")   # the counter field has 4 bits
 
 
 def S(kb, qb):
@@ -104,42 +107,43 @@ def gen_iteration(r):
     """Iteration t with t % 3 == r: K(t+1) in K slot (r+1)%3, K(t+2) in (r+2)%3, V(t) in V slot r."""
     k1, k2, v0 = ((r + 1) % 3) * TILE, ((r + 2) % 3) * TILE, r * TILE
     st = Stream()
-    valu = {s: [] for s in range(64)}
-    # exps: S00 at slots 16..23 (2 per slot), S01 at 24..31, then S10[0..7] 32..39, S11[0..7] 40..47,
-    # S10[8..15] 48..55, S11[8..15] 56..63 (1 per slot); the row-sum add of a value follows the NEXT exponential
-    # (transcendental -> VALU use needs a wait state)
+    # ---- the exponentials: ONE per MFMA gap, 64 gaps for the tile's 64 scores per lane.  Order S00, S01, S10, S11
+    # starting at slot 10 (a block is exponentiated >= 2 MFMA slots after the MFMA that completes it: S00 at slot 7,
+    # S01 at 15, S10 at 23, S11 at 31); the last ten (S11[6..15]) wrap into slots 0..9 of the NEXT iteration -- S11 is
+    # not written again before slot 24.  So at the top of an iteration S11 still holds the previous pass's raw
+    # (score - reference) values in elements 6..15, and P110 / P111 are not packed yet: ca_attn4.hip hands the loop
+    # exactly that state and completes it after the loop (CA_A4 "pending S11" in the kernel).
     order = []
-    for i in range(16):
-        order.append((16 + i // 2, 0, 0, i))
-    for i in range(16):
-        order.append((24 + i // 2, 0, 1, i))
-    for i in range(8):
-        order.append((32 + i, 1, 0, i))
-    for i in range(8):
-        order.append((40 + i, 1, 1, i))
-    for i in range(8):
-        order.append((48 + i, 1, 0, 8 + i))
-    for i in range(8):
-        order.append((56 + i, 1, 1, 8 + i))
-    pending_add = None
-    for slot, kb, qb, i in order:
-        valu[slot].append(("exp", kb, qb, i))
-        if pending_add is not None:
-            valu[slot].append(pending_add)
-        pending_add = ("add", kb, qb, i)
-    last_add = pending_add
-    # packs: P[kb][qb][sk] dword j <- (S[kb][qb][8sk+2j], S[kb][qb][8sk+2j+1]); only after the last P.V MFMA of tile t
-    # that reads P[kb][qb][sk] (slot 32 + 2*(kb*8+sk*4+3) + qb)
-    def cvts(slots, kb, sk):
-        lst = [(kb, qb, sk, j) for qb in (0, 1) for j in range(4)]
-        per = len(lst) // len(slots)
-        for n, s in enumerate(slots):
-            for c in lst[n * per:(n + 1) * per]:
-                valu[s].append(("cvt",) + c)
-    cvts([0, 1, 2, 3], 1, 1)          # of the PREVIOUS pass over S1x[8..15]: first thing in the iteration
-    cvts([40, 41, 42, 43], 0, 0)
-    cvts([48, 49, 50, 51], 0, 1)
-    cvts([58, 59, 60, 61], 1, 0)
+    n = 10
+    for kb, qb in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        for i in range(16):
+            order.append((n, kb, qb, i))
+            n += 1
+    # hipcc gives every statement AT MOST ONE written element per vector variable for free (a second tied or defined
+    # sub-register of the same tuple costs it a copy out and back), and pads an s_nop behind a statement whose output the
+    # NEXT statement reads.  So one exponential per statement, and the row-sum add of a value rides two exponentials
+    # later (also >= the one wait state a transcendental needs), into two accumulators per query block in turn
+    # (l0 / l0b, l1 / l1b): consecutive statements then never read each other's output.
+    exps_of = {s: [] for s in range(64)}
+    for n, (slot, kb, qb, i) in enumerate(order):
+        add = order[n - 2][1:] + ("" if n % 2 == 0 else "b",)      # (n < 2: the previous pass's last two values)
+        exps_of[slot % 64].append(((kb, qb, i), add))
+    WRAP_FIRST = 64 - 10     # order[54:] are issued at slots 0..9 of the next iteration
+    # ---- packs: P[kb][qb][sk] dword j <- (S[kb][qb][8sk+2j], S[kb][qb][8sk+2j+1]); after the values' exponentials and
+    # after the last P.V MFMA of tile t that reads P[kb][qb][sk] (slot 32 + 2*(kb*8+sk*4+3) + qb); at most one pack per
+    # vector variable and statement.
+    cvt_of = {s: [] for s in range(64)}
+    def cvts(slots, kb, qb, sk):
+        for j, s_ in enumerate(slots):
+            cvt_of[s_ % 64].append((kb, qb, sk, j))
+    cvts([40, 41, 42, 43], 0, 0, 0)    # S00[0..7]  exponentiated by slot 17; P000 last read at slot 38
+    cvts([40, 41, 42, 43], 0, 1, 0)    # S01[0..7]  by slot 33;              P010 at 39
+    cvts([48, 49, 50, 51], 0, 0, 1)    # S00[8..15] by 25;                   P001 at 46
+    cvts([48, 49, 50, 51], 0, 1, 1)    # S01[8..15] by 41;                   P011 at 47
+    cvts([56, 57, 58, 59], 1, 0, 0)    # S10[0..7]  by 49;                   P100 at 54
+    cvts([64, 65, 70, 71], 1, 0, 1)    # S10[8..15] by 57;                   P101 last read at slot 62 -> next iteration
+    cvts([66, 67, 68, 69], 1, 1, 0)    # S11[0..7]  by 65 (= slot 1 of the next iteration); P110 last read at slot 55
+    cvts([76, 77, 78, 79], 1, 1, 1)    # S11[8..15] by 73;                   P111 at 63
     reads = {s: [] for s in range(64)}
     for ks in range(8):
         reads[9 + ks].append(("k", ks, k1 + 8192, ks, f"k1_{ks}"))        # K(t+1) key block 1, fragment ks -> ring ks
@@ -152,12 +156,19 @@ def gen_iteration(r):
     for f in range(8, 16):
         kb, sk, db = f >> 3, (f >> 2) & 1, f & 3
         reads[34 + 2 * (f - 8)].append(("v", f - 8, v0, kb, sk, db, f"v_{f}"))
+
+    def exp_and_add(e):
+        (kb, qb, i), add = e
+        st.ins("v_exp_f32 {0}, {0}", (f"{S(kb, qb)}[{i}]", "rw"))
+        akb, aqb, ai, sfx = add
+        st.ins("v_add_f32 {0}, {0}, {1}", (f"l{aqb}{sfx}", "rw"), (f"{S(akb, aqb)}[{ai}]", "r"))
+
     st.comment(f"---- iteration variant r = {r}: K(t+1) slot {(r + 1) % 3}, K(t+2) slot {(r + 2) % 3}, V(t) slot {r}")
     for s in range(64):
         if s < 32:
             kb, qb, ks = s >> 4, (s >> 3) & 1, s & 7
-            if kb == 1 and qb == 0:
-                st.wait_for(f"k1_{ks}")
+            if kb == 1 and qb == 0 and ks % 2 == 0:
+                st.wait_for(f"k1_{ks + 1}")     # one wait per two fragments
             a = areg(AK + 4 * ks, 4)
             q = areg(AQ + 4 * (qb * 8 + ks), 4)
             if ks == 0:
@@ -167,31 +178,47 @@ def gen_iteration(r):
         else:
             f, qb = (s - 32) >> 1, (s - 32) & 1
             kb, sk, db = f >> 3, (f >> 2) & 1, f & 3
-            if qb == 0:
-                st.wait_for(f"v_{f}")
+            if qb == 0 and f % 2 == 0:
+                st.wait_for(f"v_{f + 1}")       # one wait per two fragments
             o = areg(AO + 16 * (qb * 4 + db), 16)
             v = areg(AV + 4 * (f & 7), 4)
             st.ins(f"v_mfma_f32_32x32x16_bf16 {o}, {v}, {{0}}, {o}", (f"P{kb}{qb}{sk}", "r"))
+        if s < 8:
+            # LDS-DMA of this wave's 4 + 4 pieces (1 KiB each) of K(t+3) / V(t+1), one per gap: scalar tile base + lane
+            # offset, M0 = the piece's LDS address.  (hipcc itself never uses M0 in this kernel: build.py checks that,
+            # so it is neither saved nor restored.)  DMAK / DMAV are 64-bit tile bases, LDK / LDV the LDS address of the
+            # wave's first piece; for a tile that does not exist, or that ca_attn4.hip staged the general way, they
+            # point at a valid tile and at the dump page, so no branch is needed here.
+            j, isv = s >> 1, s & 1
+            if os.environ.get("CA_A4_GEN_SKIP"):     # bisecting aid: skip the piece when the base is 0
+                st.ins("s_cmp_eq_u64 {0}, 0", ("DMAV" if isv else "DMAK", "rs"))
+                st.ins("s_cbranch_scc1 .Lca4_nodma%=")
+            st.ins(f"s_add_u32 m0, {{0}}, {1024 * j}", ("LDV" if isv else "LDK", "rs"))
+            # M0 write -> LDS-DMA: one wait state.  And the tile base: an SGPR written by SALU or VALU needs 5 wait
+            # states before a VMEM instruction may use it as its address; hipcc pads nothing inside an asm statement and
+            # may write the pair right in front of ANY of these statements (scalar bookkeeping in front of the first
+            # piece, a v_readlane reload of a spilled SGPR in front of any other).  With one state here the pieces
+            # intermittently read through a half-updated base (address 0xffff....: a fault that came and went).
+            st.ins("s_nop 4")
+            st.ins("global_load_lds_dwordx4 {0}, {1}", (f"{'voff' if isv else 'koff'}{j}", "r"),
+                   ("DMAV" if isv else "DMAK", "rs"))
+            if os.environ.get("CA_A4_GEN_SKIP"):
+                st.ins(".Lca4_nodma%=:")
         for rd in reads[s]:
             if rd[0] == "k":
                 st.read_k(rd[1], rd[2], rd[3], rd[4])
             else:
                 st.read_v(rd[1], rd[2], rd[3], rd[4], rd[5], rd[6])
-        for v in valu[s]:
-            if v[0] == "exp":
-                _, kb, qb, i = v
-                st.ins("v_exp_f32 {0}, {0}", (f"{S(kb, qb)}[{i}]", "rw"))
-            elif v[0] == "add":
-                _, kb, qb, i = v
-                st.ins("v_add_f32 {0}, {0}, {1}", (f"l{qb}", "rw"), (f"{S(kb, qb)}[{i}]", "r"))
-            else:
-                _, kb, qb, sk, j = v
-                st.ins("v_cvt_pk_bf16_f32 {0}, {1}, {2}", (f"P{kb}{qb}{sk}[{j}]", "w"),
-                       (f"{S(kb, qb)}[{8 * sk + 2 * j}]", "r"), (f"{S(kb, qb)}[{8 * sk + 2 * j + 1}]", "r"))
-        if s == 63:
-            _, kb, qb, i = last_add
-            st.ins("s_nop 0")
-            st.ins("v_add_f32 {0}, {0}, {1}", (f"l{qb}", "rw"), (f"{S(kb, qb)}[{i}]", "r"))
+        st.flush()      # statement A: wait, MFMA, LDS reads, DMA.  Statement B: the VALU fillers -- with a statement
+                        # between two MFMAs of one accumulation chain hipcc has no reason to pad an s_nop between them
+        seen = set()
+        for (kb, qb, sk, j) in cvt_of[s]:
+            assert (kb, qb, sk) not in seen        # one written element per vector variable and statement
+            seen.add((kb, qb, sk))
+            st.ins("v_cvt_pk_bf16_f32 {0}, {1}, {2}", (f"P{kb}{qb}{sk}[{j}]", "w"),
+                   (f"{S(kb, qb)}[{8 * sk + 2 * j}]", "r"), (f"{S(kb, qb)}[{8 * sk + 2 * j + 1}]", "r"))
+        assert len(exps_of[s]) == 1
+        exp_and_add(exps_of[s][0])
         st.flush()
     return st.lines
 
@@ -214,14 +241,14 @@ def gen_helpers():
         L.append(f'  asm volatile("v_accvgpr_write_b32 a{AO + i}, 0"); \\')
     L.append('  asm volatile("s_nop 7"); } while (0)')
     L.append("")
-    # ---- O -> VGPRs (epilogue): of[qb][db] f32x16
-    L.append("#define CA_A4_READ_O(of) do { asm volatile(\"s_nop 15\\n\\ts_nop 7\"); \\")
+    # ---- O -> VGPRs (epilogue), one query block at a time: of[db] f32x16
     for qb in range(2):
+        L.append(f"#define CA_A4_READ_O{qb}(of) do {{ asm volatile(\"s_nop 15\\n\\ts_nop 7\"); \\")
         for db in range(4):
             for r in range(16):
-                L.append(f'  asm volatile("v_accvgpr_read_b32 %0, a{AO + 16 * (qb * 4 + db) + r}" : "=v"(of[{qb}][{db}][{r}])); \\')
-    L.append("  } while (0)")
-    L.append("")
+                L.append(f'  asm volatile("v_accvgpr_read_b32 %0, a{AO + 16 * (qb * 4 + db) + r}" : "=v"(of[{db}][{r}])); \\')
+        L.append("  } while (0)")
+        L.append("")
     # ---- O *= alpha (safe path only): al0 / al1 per query block
     L.append("#define CA_A4_SCALE_O(al0, al1) do { float t_; asm volatile(\"s_nop 15\\n\\ts_nop 7\"); \\")
     for qb in range(2):
@@ -279,7 +306,7 @@ def main():
            "// Part 1 (CA_A4_HELPERS): straight-line building blocks; part 2 (CA_A4_SCHEDULE): one pipelined tile of",
            "// ca_attn4_kernel, included inside the tile loop with these names in scope:",
            "//   f32x16 S00,S01,S10,S11 (scores / fp32 P), NM0,NM1 (-reference), i32x4 P000..P111 (bf16 P fragments),",
-           "//   float l0,l1 (row sums), uint32_t ka0..ka7 (K fragment addresses), va00..va13 (V fragment addresses,",
+           "//   float l0,l0b,l1,l1b (row sums, two accumulators per query block), uint32_t ka0..ka7 (K fragment addresses), va00..va13 (V fragment addresses,",
            "//   V ring base included), int R (t % 3).",
            "// A counted lgkmcnt(N) for read X: N = the reads issued after X (the LDS returns data in order).",
            "", "#ifdef CA_A4_HELPERS"]
