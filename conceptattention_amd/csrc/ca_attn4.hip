@@ -273,6 +273,31 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
   if (nt > 2) stage(2, 2, false);
   drain_and_barrier();
 
+#ifdef CA_A4_PLAIN   // bisecting aid: every tile the plain way (no pipelined stream), same prologue and epilogue
+  if (active) {
+    CA_A4_QK_PLAIN_ZERO(0u);
+    if (nt_full == 0) mask_tail(0);
+    float x0, x1;
+    row_max(x0, x1);
+    set_reference(x0, x1);
+    exp_sum(x0, x1);
+    pack_all();
+    CA_A4_PV_PLAIN(0u);
+  }
+  for (int t = 1; t < nt; ++t) {
+    drain_and_barrier();
+    stage(t, 0, false);
+    stage(t, 0, true);
+    drain_and_barrier();
+    if (active) {
+      CA_A4_QK_PLAIN_NEGM(0u);
+      if (ragged && t == nt - 1) mask_tail(t);
+      exp_sum(0.f, 0.f);
+      pack_all();
+      CA_A4_PV_PLAIN(0u);
+    }
+  }
+#else
   // ---- tile 0 sets the reference (the only tile whose maximum is computed)
   if (active) {
     CA_A4_QK_PLAIN_ZERO(0u);
@@ -401,6 +426,7 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
     }
   }
 
+#endif  // CA_A4_PLAIN
   // ---- did any row leave the safe range?  (workgroup-uniform decision: the recomputation stages tiles together)
   int *flag = (int *)(smem + a4::FLAG_OFF);
   if (tid == 0) *flag = 0;
