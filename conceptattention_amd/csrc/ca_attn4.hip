@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
   const uint32_t dump_dst = lds0 + a4::DUMP_OFF + wave * 4096;
   auto uni64 = [&](const void *p) {
     const uint64_t b = (uint64_t)(uintptr_t)p;
-    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)b);
+    // (the builtin returns int: without the casts the low half is SIGN-extended into the high one -- a base whose bit 31
+    // is set became 0xffffffff........, a memory fault that came and went with the allocation addresses)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
   };
   const uint64_t kb0 = uni64(k0p), kb1 = uni64(k1p), vb0 = uni64(v0p), vb1 = uni64(v1p);
   const uint64_t row_bytes = (uint64_t)(uint32_t)ldkv * 2u;
