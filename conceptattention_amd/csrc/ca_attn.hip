@@ -380,9 +380,10 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   // Default: 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: ~250 us for
   // 4352x4352x24 heads on MI355X.  A/B aid (same numerics): CA_ATTN_WAVES=4 = 128-row workgroups.
   static const int nw = (getenv("CA_ATTN_WAVES") && atoi(getenv("CA_ATTN_WAVES")) == 4) ? 4 : 8;
-  // pre-scaled q: CA_ATTN_KERNEL=4 selects the one-wave-per-SIMD kernel (ca_attn4.hip; 4 waves x 64 rows = 256 rows per
-  // workgroup as well, same numerics contract); default: the two-waves-per-SIMD kernel below
-  static const bool want4 = getenv("CA_ATTN_KERNEL") && atoi(getenv("CA_ATTN_KERNEL")) == 4;
+  // pre-scaled q (the model path): the one-wave-per-SIMD kernel (ca_attn4.hip; 4 waves x 64 rows = 256 rows per workgroup
+  // as well, same numerics contract).  A/B aid: CA_ATTN_KERNEL=8 sends pre-scaled q through the two-waves-per-SIMD
+  // kernel below, which also serves every call that passes a scale.
+  static const bool want4 = !(getenv("CA_ATTN_KERNEL") && atoi(getenv("CA_ATTN_KERNEL")) == 8);
   const bool use4 = pre && want4;
   const int qrows = use4 ? 256 : nw * 32;
   AttnLaunch L = {};

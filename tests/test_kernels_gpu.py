@@ -204,12 +204,13 @@ def test_attention_repeatable_and_persistent_gemm_multi_round():
     q, k, v = buf[:, :3072], buf[:, 3072:6144], buf[:, 6144:]
     probs = lambda o: [ops.Attn(q[C:], o[C:], k[C:], v[C:]),
                        ops.Attn(q[:C], o[:C], k[:C], v[:C], k[C + 256:], v[C + 256:])]
-    first = torch.zeros(C + n, 3072, device=DEV, dtype=torch.bfloat16)
-    ops.attention(probs(first), nh)
-    for i in range(10):
-        out = torch.zeros_like(first)
-        ops.attention(probs(out), nh)
-        assert torch.equal(out, first), f"attention launch {i} differs"
+    for kw in ({}, {"q_prescaled": True}):          # ca_attn_kernel, then ca_attn4_kernel (q values merely differ in scale)
+        first = torch.zeros(C + n, 3072, device=DEV, dtype=torch.bfloat16)
+        ops.attention(probs(first), nh, **kw)
+        for i in range(10):
+            out = torch.zeros_like(first)
+            ops.attention(probs(out), nh, **kw)
+            assert torch.equal(out, first), f"attention launch {i} differs ({kw})"
     # 864 tiles in one grouped launch = 3.4 rounds on 256 CUs (the mlp.0 launch of a double block)
     a0, a1 = rnd(4096, 3072), rnd(260, 3072, seed=1)
     w0, w1 = rnd(12288, 3072, scale=0.02), rnd(12288, 3072, scale=0.02, seed=1)
@@ -265,15 +266,33 @@ def attn_ref(q, k, v, nh):
     return (w @ vh).transpose(0, 1).reshape(q.shape[0], nh * 128)
 
 
-@pytest.mark.parametrize("nq,nk", [(300, 200), (32, 64), (7, 1), (513, 1000)])
-def test_attention_ragged(nq, nk):
+SL2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+
+
+def attn_forms(q, prescaled):
+    """(q to hand to the kernel, q the kernel effectively uses, kwargs): with ``prescaled`` the q rows carry
+    softmax_scale * log2(e) (CA_ATTN_Q_PRESCALED -> ca_attn4_kernel, the model path's kernel); otherwise the kernel
+    scales (ca_attn_kernel)."""
+    if not prescaled:
+        return q, q, {}
+    qp = (q.float() * SL2).bfloat16()
+    return qp, qp.float() / SL2, {"q_prescaled": True}
+
+
+PRESCALED = pytest.mark.parametrize("prescaled", [False, True], ids=["scaling-kernel", "prescaled-attn4"])
+
+
+@PRESCALED
+@pytest.mark.parametrize("nq,nk", [(300, 200), (32, 64), (7, 1), (513, 1000), (70, 64), (64, 129), (257, 448)])
+def test_attention_ragged(nq, nk, prescaled):
     nh = 3
     qkv_q = rnd(nq, 3 * nh * 128)
     qkv_k = rnd(nk, 3 * nh * 128, seed=1)
     q, k, v = qkv_q[:, :nh * 128], qkv_k[:, nh * 128:2 * nh * 128], qkv_k[:, 2 * nh * 128:]
     out = torch.zeros(nq, nh * 128, device=DEV, dtype=torch.bfloat16)
-    ops.attention([ops.Attn(q, out, k, v)], nh)
-    close(out, attn_ref(q, k, v, nh), atol=1e-2)
+    qk, qe, kw = attn_forms(q, prescaled)
+    ops.attention([ops.Attn(qk, out, k, v)], nh, **kw)
+    close(out, attn_ref(qe, k, v, nh), atol=1e-2)
 
 
 def test_attention_two_segments_and_two_problems():
@@ -297,46 +316,55 @@ def test_attention_two_segments_and_two_problems():
     assert (out32 - attn_ref(q[:C], kc, vc, nh)).abs().max() < 8e-3
 
 
-def test_attention_online_softmax_rescale_spike():
-    """A key far down the sequence dominates one query row: the running max must jump at that tile."""
-    nh, nq, nk = 1, 64, 640
+@PRESCALED
+@pytest.mark.parametrize("gain", [4.0, 9.0])
+def test_attention_online_softmax_rescale_spike(gain, prescaled):
+    """A key far down the sequence dominates one query row: the running max must jump at that tile.  gain 4 = ~65
+    octaves above the row's tile-0 reference: ca_attn_kernel redoes the tile, ca_attn4_kernel (no per-tile check) sees
+    a row sum > 2^60 at the end and recomputes the workgroup's rows the classical way; gain 9 = ~146 octaves: the
+    kept-reference pass overflows to inf on the way, which the same final check catches."""
+    nh, nq, nk = 1, 300, 640
     q, k, v = rnd(nq, 128), rnd(nk, 128, seed=3), rnd(nk, 128, seed=4)
-    k[500] = (q[17].float() * 4).bfloat16()  # logit ~ 4*|q|^2/sqrt(128) >> others
+    k[500] = (q[17].float() * gain).bfloat16()  # logit ~ gain*|q|^2/sqrt(128) >> others
+    k[70] = (q[290].float() * gain).bfloat16()  # a second workgroup, an early tile
     out = torch.zeros(nq, 128, device=DEV, dtype=torch.bfloat16)
-    ops.attention([ops.Attn(q, out, k, v)], nh)
-    close(out, attn_ref(q, k, v, nh), atol=1e-2)
+    qk, qe, kw = attn_forms(q, prescaled)
+    ops.attention([ops.Attn(qk, out, k, v)], nh, **kw)
+    close(out, attn_ref(qe, k, v, nh), atol=1e-2)
 
 
-@pytest.mark.parametrize("alpha", [1.0, 1.45, 1.9])    # logit gap to the tile-0 reference ~ 16 / 24 / 31 octaves
+@PRESCALED
+@pytest.mark.parametrize("alpha", [1.0, 1.45, 1.9, 3.6])    # logit gap to the tile-0 reference ~ 16 / 24 / 31 / 59 octaves
 @pytest.mark.parametrize("where", ["late_full_tile", "masked_tail_tile", "segment_1", "segment_1_tail"])
-def test_attention_kept_reference_band_spikes(alpha, where):
+def test_attention_kept_reference_band_spikes(alpha, where, prescaled):
     """The softmax reference of a row is set by tile 0 and then KEPT; a tile is redone only when a partial row sum
     exceeds 2^30.  These spikes sit in the band the 65-octave spike test above does NOT reach: a late key 16-31
     octaves above the tile-0 reference (alpha * |q|^2 / sqrt(128) * log2 e), i.e. P up to ~2^29 WITHOUT a redo
     (alpha 1.0, 1.45) and just across the redo limit (1.9) -- in a full tile, in the ragged (masked) last tile, and
     in the second key segment (its full and its ragged tile).  fp32 reference, the tolerance of the other tests."""
     nh, nq = 1, 96
-    q = rnd(nq, 128)
+    q0 = rnd(nq, 128)
+    q, qe, kw = attn_forms(q0, prescaled)      # (the spikes are built from the unscaled q0)
     if where in ("late_full_tile", "masked_tail_tile"):
         nk = 640 if where == "late_full_tile" else 650           # 650: tile 10 has 10 valid keys
         k, v = rnd(nk, 128, seed=3), rnd(nk, 128, seed=4)
         pos = 500 if where == "late_full_tile" else 645
-        k[pos] = (q[17].float() * alpha).bfloat16()
-        k[pos - 130] = (q[70].float() * alpha * 0.9).bfloat16()   # a second row, another wave, another tile
+        k[pos] = (q0[17].float() * alpha).bfloat16()
+        k[pos - 130] = (q0[70].float() * alpha * 0.9).bfloat16()   # a second row, another wave, another tile
         probs, kk, vv = (lambda o: [ops.Attn(q, o, k, v)]), k, v
     else:
         n0, n1 = 100, 540 if where == "segment_1" else 533       # 633 keys: the last tile is ragged AND in segment 1
         k0, v0, k1, v1 = rnd(n0, 128, seed=3), rnd(n0, 128, seed=4), rnd(n1, 128, seed=5), rnd(n1, 128, seed=6)
         pos = 400 if where == "segment_1" else n1 - 3
-        k1[pos] = (q[17].float() * alpha).bfloat16()
-        k1[7] = (q[70].float() * alpha * 0.9).bfloat16()          # tile 1 = the tile that straddles the two segments
+        k1[pos] = (q0[17].float() * alpha).bfloat16()
+        k1[7] = (q0[70].float() * alpha * 0.9).bfloat16()          # tile 1 = the tile that straddles the two segments
         probs, kk, vv = (lambda o: [ops.Attn(q, o, k0, v0, k1, v1)]), torch.cat((k0, k1)), torch.cat((v0, v1))
     out = torch.zeros(nq, 128, device=DEV, dtype=torch.bfloat16)
-    ops.attention(probs(out), nh)
-    ref = attn_ref(q, kk, vv, nh)
+    ops.attention(probs(out), nh, **kw)
+    ref = attn_ref(qe, kk, vv, nh)
     close(out, ref, atol=1e-2)
     # the spiked rows are (nearly) one-hot on the spike's value row: check them against it directly as well
-    s17 = (q[17].float() @ kk.float().t() / math.sqrt(128)).softmax(0)
+    s17 = (qe[17].float() @ kk.float().t() / math.sqrt(128)).softmax(0)
     assert s17.max() > 0.95
     if s17.max() > 0.995:
         assert (out[17].float() - vv[int(s17.argmax())].float()).abs().max() < 5e-2
@@ -435,13 +463,18 @@ def test_heatmap_logits_fp32_image_vectors():
         ops.heatmap_logits(iv, cv.bfloat16(), lg)               # fp32 image vectors go with fp32 concept vectors
 
 
-def test_attention_full_size():
+@PRESCALED
+def test_attention_full_size(prescaled):
     """24 heads, 4352 rows (T=256 + L=4096) read in place from a [rows, 9216] projection buffer."""
     nh, n = 24, 4352
     buf = rnd(n, 9216)
+    if prescaled:
+        buf[:, :3072] = (buf[:, :3072].float() * SL2).bfloat16()
     q, k, v = buf[:, :3072], buf[:, 3072:6144], buf[:, 6144:]
     out = torch.zeros(n, 3072, device=DEV, dtype=torch.bfloat16)
-    ops.attention([ops.Attn(q, out, k, v)], nh)
+    ops.attention([ops.Attn(q, out, k, v)], nh, **({"q_prescaled": True} if prescaled else {}))
+    if prescaled:
+        q = q.float() / SL2
     ref = torch.cat([attn_ref(q[i:i + 1088], k, v, nh) for i in range(0, n, 1088)])
     close(out, ref, atol=5e-3)
 

@@ -27,6 +27,13 @@ def attn():
     return o
 
 
+def attn4():
+    o = torch.zeros(C + n, 3072, device=dev, dtype=torch.bfloat16)
+    ops.attention([ops.Attn(q[C:], o[C:], k[C:], v[C:]), ops.Attn(q[:C], o[:C], k[:C], v[:C], k[C + 256:], v[C + 256:])], nh,
+                  q_prescaled=True)
+    return o
+
+
 def mlp0():
     o0 = torch.empty(4096, 12288, device=dev, dtype=torch.bfloat16)
     o1 = torch.empty(260, 12288, device=dev, dtype=torch.bfloat16)
@@ -56,7 +63,7 @@ def thin_rows():  # 5 full row tiles in the ping-pong walk + 20 rows in the thin
     return x
 
 
-cases = {"thin rows (mlp.2 shape)": thin_rows, "attention": attn, "mlp0 (grouped, persistent)": mlp0, "linear2 (K=15360)": linear2, "fp8 gemm": fp8}
+cases = {"thin rows (mlp.2 shape)": thin_rows, "attention": attn, "attention (pre-scaled q: ca_attn4_kernel)": attn4, "mlp0 (grouped, persistent)": mlp0, "linear2 (K=15360)": linear2, "fp8 gemm": fp8}
 first = {name: fn() for name, fn in cases.items()}
 torch.cuda.synchronize()
 bad = {name: 0 for name in cases}
