@@ -41,6 +41,7 @@ def audit_attn4(asm_path: str) -> None:
                 ("accvgpr" in line or re.search(r"\ba\[?\d", line.split(";")[0]) or
                  re.search(r"\bm0\b", line.split(";")[0])):   # (M0: the tile loop's LDS-DMA writes it without saving it)
             bad.append(line.strip())
+    bad += audit_sgpr_hazards(text)
     m = re.search(r"\.vgpr_spill_count:\s*(\d+)", text)
     scratch = re.search(r"\.private_segment_fixed_size:\s*(\d+)", text)
     if bad or (m and int(m.group(1))) or (scratch and int(scratch.group(1))):
@@ -49,6 +50,52 @@ def audit_attn4(asm_path: str) -> None:
     for tmp in os.listdir(HERE):   # -save-temps leftovers
         if tmp.startswith("ca_attn4-") and not tmp.endswith(".s"):
             os.remove(os.path.join(HERE, tmp))
+
+
+def audit_sgpr_hazards(text: str) -> list:
+    """hipcc pads no hazard of an instruction INSIDE an asm statement.  The one the tile loop's LDS-DMA pieces are
+    exposed to: an SGPR written by a VALU instruction (v_readlane = the reload of a spilled SGPR, v_readfirstlane,
+    v_cmp) needs 5 wait states before a VMEM instruction reads it (SALU-written SGPRs are interlocked); M0 needs one
+    state between its write and the LDS-DMA.  Straight-line check of every asm VMEM instruction against the 5
+    instructions in front of it (s_nop N counts N + 1)."""
+    import re
+    def sregs(tok):
+        out = set()
+        for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", tok):
+            out |= set(range(int(a), int(b) + 1))
+        out |= {int(x) for x in re.findall(r"\bs(\d+)\b", tok)}
+        return out
+    hist, bad, inside = [], [], False      # hist: (wait states, VALU-written SGPRs, writes M0, text)
+    for line in text.split("\n"):
+        code = line.split(";")[0].strip()
+        if "#ASMSTART" in line:
+            inside = True
+            continue
+        if "#ASMEND" in line:
+            inside = False
+            continue
+        if not code or code.endswith(":") or code.startswith("."):
+            continue
+        op = code.split()[0]
+        args = code[len(op):]
+        if inside and op.startswith(("buffer_", "global_", "flat_")):
+            need, states = sregs(args), 0
+            for ws, written, wm0, txt in reversed(hist):
+                if states >= 5:
+                    break
+                if written & need:
+                    bad.append(f"{txt} -> {code} ({states} wait states)")
+                if wm0 and states < 1 and " lds" in code + " ":
+                    bad.append(f"{txt} -> {code} (M0, {states} wait states)")
+                states += ws
+        ws = int(args.split()[0], 0) + 1 if op == "s_nop" else 1
+        first = args.split(",")[0]
+        valu_sgpr_write = sregs(first) if op.startswith("v_") else set()
+        if op.startswith("v_cmp") and "_e64" not in op and "s" not in first:
+            valu_sgpr_write = set()                                    # writes VCC
+        hist.append((ws, valu_sgpr_write, re.search(r"\bm0\b", first) is not None, code))
+        hist = hist[-12:]
+    return bad
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
   int prob = 0;
   while (prob + 1 < L.n_problems && bid >= L.blk_end[prob]) ++prob;
   if (prob) bid -= L.blk_end[prob - 1];
-  const int nqb = L.nqb[prob];
+  prob = __builtin_amdgcn_readfirstlane(prob);
+  const int nqb = __builtin_amdgcn_readfirstlane(L.nqb[prob]);
   const int xg = bid & 7, idx = bid >> 3;
   const int head = xg + 8 * (idx / nqb);
   const int qb_wg = idx % nqb;
@@ -69,8 +70,11 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
   // the descriptor's fields as scalars (indexing the by-value argument inside the loop would make hipcc keep a scratch
   // copy of it, and scalar loads inside the tile loop would share the LDS reads' counter)
   const ca_attn_problem &P = L.p[prob];
-  const int nq = P.nq, n0 = P.n0, nkeys = P.n0 + P.n1, nq0 = P.nq0;
-  const int ldkv = P.ldkv, ldq = P.ldq, ldo = P.ldo, ldo32 = P.ldo32;
+  // (through readfirstlane: the descriptor is indexed with a run-time problem number, and what hipcc cannot prove
+  // wave-uniform it will not put into the SGPR operands of the tile loop's asm statements)
+  auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+  const int nq = uni(P.nq), n0 = uni(P.n0), nkeys = uni(P.n0 + P.n1), nq0 = uni(P.nq0);
+  const int ldkv = uni(P.ldkv), ldq = uni(P.ldq), ldo = uni(P.ldo), ldo32 = uni(P.ldo32);
   const bf16 *q_a = (const bf16 *)P.q, *q_b = (const bf16 *)P.q1;
   bf16 *o_a = (bf16 *)P.out, *o_b = (bf16 *)P.out1;
   float *o32 = P.out_f32;
@@ -124,6 +128,11 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
       for (int j = 0; j < 4; ++j) ca_glds16_asm_s(base, is_v ? voff[j] : koff[j], dst + (wave * 4 + j) * 1024);
       return;
     }
+    // (rare path, inlined at every tile event of the loop: its per-lane values are derived from a laundered lane id so
+    // that hipcc cannot hoist them out of the tile loop, where they would cost registers the stream needs)
+    int lane_l = lane;
+    asm volatile("" : "+v"(lane_l));
+    const int st_row = lane_l >> 4, st_cp = lane_l & 15;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = 4 * (wave * 4 + j) + st_row;
@@ -134,66 +143,69 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
       ca_glds16_asm((s0 ? p0 : p1) + ro + (ch << 3), dst + (wave * 4 + j) * 1024);
     }
   };
-  // The tile loop issues its LDS-DMA from inside the instruction stream (one piece per MFMA gap, scalar tile base + the
-  // lane offsets koff / voff, no branch): tile bases and LDS destinations of the next K / V tile for that form.  A tile
-  // that straddles the two key segments or is ragged is staged here, the general way; for it, and for a tile past the
-  // end, the stream's pieces re-read a tile that is known to be addressable (SAFE: the first of tiles 0 and 1 that lies
-  // inside one segment -- the loop only runs when both are full tiles, and a segment boundary cuts at most one of them)
-  // into the dump page.  Everything here is wave-uniform scalar arithmetic (about a dozen SALU instructions per tile).
-  uint64_t DMAK = 0, DMAV = 0;
-  uint32_t LDK = 0, LDV = 0;
+  // The tile loop issues its LDS-DMA from inside the instruction stream (one 1-KiB piece per odd MFMA gap 1..15, no
+  // branch): buffer_load ... lds with a buffer descriptor per matrix, the tile's byte offset as the scalar offset and
+  // the lane offsets koff / voff.  Descriptor of a key segment: base = the address key index 0 WOULD have (segment 1:
+  // k1 - n0 rows), so that the scalar offset of tile i is i x 64 rows x row bytes in both segments and advances by one
+  // s_add per tile; the record count is unlimited (every tile sent this way lies inside its segment).  A tile that
+  // straddles the two segments or is ragged is staged the general way (stage()), a tile past the end not at all: for
+  // those the stream's pieces get the NULL descriptor (0 records: nothing is read) and land in the dump page.  The
+  // per-tile bookkeeping is a compare against the index of the next tile at which any of this changes (EVK / EVV);
+  // everything else happens in the rare k_event / v_event.
   const uint32_t koff0 = koff[0], koff1 = koff[1], koff2 = koff[2], koff3 = koff[3];
   const uint32_t voff0 = voff[0], voff1 = voff[1], voff2 = voff[2], voff3 = voff[3];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(ca_lptr)smem;
-  const uint32_t dump_dst = lds0 + a4::DUMP_OFF + wave * 4096;
-  auto uni64 = [&](const void *p) {
-    const uint64_t b = (uint64_t)(uintptr_t)p;
-    // (the builtin returns int: without the casts the low half is SIGN-extended into the high one -- a base whose bit 31
-    // is set became 0xffffffff........, a memory fault that came and went with the allocation addresses)
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-    return ((uint64_t)hi << 32) | (uint64_t)lo;
+  auto uni32 = [&](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+  auto make_desc = [&](const bf16 *key0_addr, uint32_t records) {
+    const uint64_t b = (uint64_t)(uintptr_t)key0_addr;
+    return i32x4{(int)uni32((uint32_t)b), (int)(uni32((uint32_t)(b >> 32)) & 0xffffu), (int)records, 0x00020000};
   };
-  const uint64_t kb0 = uni64(k0p), kb1 = uni64(k1p), vb0 = uni64(v0p), vb1 = uni64(v1p);
-  const uint64_t row_bytes = (uint64_t)(uint32_t)ldkv * 2u;
-  auto tile_base = [&](int tile, bool is_v, bool &fast) -> uint64_t {   // base of a tile that lies inside one segment
-    const int lo = tile * KV_TILE;
-    const bool in0 = lo + KV_TILE <= n0, in1 = lo >= n0 && lo + KV_TILE <= nkeys;
-    fast = in0 || in1;
-    return (in0 ? (is_v ? vb0 : kb0) : (is_v ? vb1 : kb1)) + (uint64_t)(uint32_t)(in0 ? lo : lo - n0) * row_bytes;
+  const uint32_t row_bytes = (uint32_t)ldkv * 2u, tile_step = 64u * row_bytes;
+  const i32x4 dsk0 = make_desc(k0p, 0xffffffffu), dsv0 = make_desc(v0p, 0xffffffffu);
+  const i32x4 dsk1 = make_desc(k1p - (size_t)n0 * ldkv, 0xffffffffu), dsv1 = make_desc(v1p - (size_t)n0 * ldkv, 0xffffffffu);
+  const i32x4 ds_null = make_desc(k0p, 0u);
+  const int t_straddle = (n0 & (KV_TILE - 1)) && n0 < nkeys ? n0 / KV_TILE : -1;   // the tile with keys of both segments
+  const int t_seg1 = (n0 + KV_TILE - 1) / KV_TILE;                                  // first tile inside segment 1
+  const uint32_t lw = lds0 + wave * 4096, lw_dump = lds0 + a4::DUMP_OFF + wave * 4096;
+  i32x4 DSK = ds_null, DSV = ds_null;
+  uint32_t SOK = 0, SOV = 0, LWK = lw, LWV = lw;
+  int EVK = 3, EVV = 1;     // the first iteration's tiles are events (they set the state up)
+  // tile `tile` is about to be sent into ring slot `slot` (dst_off = the slot's byte offset as the stream's M0 immediate
+  // has it): sets descriptor / offset / destination for the stream's pieces, stages the tile here if it is not a
+  // full tile inside one segment, and returns the next tile index at which to come back
+  auto dma_event = [&](int tile, int slot, bool is_v, uint32_t dst_off, i32x4 &DS, uint32_t &SO, uint32_t &LW) -> int {
+    const bool fast = tile < nt_full && tile != t_straddle;
+    if (!fast) {
+      if (tile < nt) stage(tile, slot, is_v);
+      DS = ds_null, SO = 0, LW = lw_dump - dst_off;
+      return tile + 1;
+    }
+    const bool seg1 = tile >= t_seg1;
+    DS = is_v ? (seg1 ? dsv1 : dsv0) : (seg1 ? dsk1 : dsk0);
+    SO = (uint32_t)tile * tile_step;
+    LW = lw;
+    int next = nt_full;
+    if (t_straddle > tile) next = min(next, t_straddle);
+    if (t_seg1 > tile) next = min(next, t_seg1);
+    return next;
   };
-  uint64_t safe_k = kb0, safe_v = vb0;
-  {
-    bool f0;
-    const uint64_t k_t0 = tile_base(0, false, f0), v_t0 = tile_base(0, true, f0);
-    bool f1;
-    const uint64_t k_t1 = tile_base(1, false, f1), v_t1 = tile_base(1, true, f1);
-    safe_k = f0 ? k_t0 : k_t1, safe_v = f0 ? v_t0 : v_t1;   // (only used when the loop runs: then f0 || f1)
-  }
-  auto dma_prepare = [&](int tile, int slot, bool is_v) {
-    bool fast;
-    const uint64_t b = tile_base(tile, is_v, fast);
-    fast = fast && tile < nt;
-    if (tile < nt && !fast) stage(tile, slot, is_v);
-#ifdef CA_A4_SKIP_DMA   // bisecting aid (with CA_A4_GEN_SKIP=1 in the generator): base 0 = the stream skips the pieces
-    const uint64_t base = fast ? b : 0;
-#else
-    const uint64_t base = fast ? b : (is_v ? safe_v : safe_k);
-#endif
-    const uint32_t dst = fast ? lds0 + (is_v ? a4::V_BASE : 0) + slot * TILE_BYTES + wave * 4096 : dump_dst;
-    if (is_v) DMAV = base, LDV = dst;
-    else DMAK = base, LDK = dst;
-  };
-  auto stage_pieces = [&]() {   // the same 8 pieces from a wave that computes nothing (its query rows do not exist)
-    auto piece = [&](uint64_t base, uint32_t off, uint32_t dst) {
-      uint32_t keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+#define CA_A4_BOOKKEEPING(R_)                                                                                          \
+  do {                                                                                                                 \
+    if (__builtin_expect(t + 3 == EVK, 0))                                                                        \
+      EVK = dma_event(t + 3, (R_), false, (uint32_t)((R_) * TILE_BYTES), DSK, SOK, LWK);                               \
+    if (__builtin_expect(t + 1 == EVV, 0))                                                                        \
+      EVV = dma_event(t + 1, ((R_) + 1) % 3, true, (uint32_t)(a4::V_BASE + (((R_) + 1) % 3) * TILE_BYTES), DSV, SOV, LWV); \
+  } while (0)
+#define CA_A4_ADVANCE() do { SOK += tile_step; SOV += tile_step; } while (0)
+  auto stage_pieces = [&](uint32_t kdst_off, uint32_t vdst_off) {   // the same 8 pieces from a wave that computes nothing
+    auto piece = [&](const i32x4 &ds, uint32_t so, uint32_t off, uint32_t dst) {   // (its query rows do not exist)
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                   : : "v"(off), "s"(ds), "s"(so), "s"(dst) : "memory");
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (DMAK) piece(DMAK, koff[j], LDK + 1024 * j);
-      if (DMAV) piece(DMAV, voff[j], LDV + 1024 * j);
+      piece(DSK, SOK, koff[j], LWK + kdst_off + 1024 * j);
+      piece(DSV, SOV, voff[j], LWV + vdst_off + 1024 * j);
     }
   };
   auto drain_and_barrier = [&]() {   // this wave's DMA has landed, its LDS reads have returned; then everyone's
@@ -310,22 +322,17 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
     row_max(x0, x1);
     set_reference(x0, x1);
     // ... and leaves the tile in the state every iteration of the loop below starts from (the loop's softmax runs one
-    // exponential per MFMA gap and laps into the next iteration, ca_attn4_sched.inc): everything exponentiated, summed
-    // and packed EXCEPT  S11[6..15] still raw (score - reference),  S11[4], S11[5] not yet in the row sum,
-    // P101 / P110 / P111 not packed.  finish_pending() completes that state behind the loop.
+    // exponential per MFMA gap and laps into the next iteration, ca_attn4_sched.inc): S00, S01, S10 exponentiated,
+    // summed (except S10[14], S10[15]: their adds ride in the next iteration's first two gaps) and packed except P101;
+    // S11 still raw (score - reference), P110 / P111 not packed.  finish_pending() completes that state behind the loop.
     float r0 = 0.f, r1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       S00[r] = __builtin_amdgcn_exp2f(S00[r] - x0), S10[r] = __builtin_amdgcn_exp2f(S10[r] - x0);
       S01[r] = __builtin_amdgcn_exp2f(S01[r] - x1);
-      r0 += S00[r] + S10[r];
+      r0 += S00[r] + (r < 14 ? S10[r] : 0.f);
       r1 += S01[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (r < 6) S11[r] = __builtin_amdgcn_exp2f(S11[r] - x1);
-      else S11[r] = S11[r] - x1;
-      if (r < 4) r1 += S11[r];
+      S11[r] = S11[r] - x1;
     }
     l0 += r0, l1 += r1;
     pack_one(P000, S00, 0), pack_one(P001, S00, 8), pack_one(P010, S01, 0), pack_one(P011, S01, 8);
@@ -346,54 +353,53 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
 #endif
   int t = 0;
   while (t + 3 <= T) {
-    { constexpr int R = 0; CA_A4_T(ts0); dma_prepare(t + 3, 0, false); dma_prepare(t + 1, 1, true); CA_A4_T(ts1);
+    { constexpr int R = 0; (void)R; CA_A4_T(ts0); CA_A4_BOOKKEEPING(0); CA_A4_T(ts1);
       if (active) {
 #define CA_A4_SCHEDULE
 #include "ca_attn4_sched.inc"
 #undef CA_A4_SCHEDULE
-      } else {
-        stage_pieces();
+      } else {   // a wave whose query rows do not exist: its share of the staging only
+        stage_pieces((uint32_t)(0 * TILE_BYTES), (uint32_t)(a4::V_BASE + ((0 + 1) % 3) * TILE_BYTES));
       }
-      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
-    { constexpr int R = 1; CA_A4_T(ts0); dma_prepare(t + 3, 1, false); dma_prepare(t + 1, 2, true); CA_A4_T(ts1);
+      CA_A4_ADVANCE(); CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
+    { constexpr int R = 1; (void)R; CA_A4_T(ts0); CA_A4_BOOKKEEPING(1); CA_A4_T(ts1);
       if (active) {
 #define CA_A4_SCHEDULE
 #include "ca_attn4_sched.inc"
 #undef CA_A4_SCHEDULE
-      } else {
-        stage_pieces();
+      } else {   // a wave whose query rows do not exist: its share of the staging only
+        stage_pieces((uint32_t)(1 * TILE_BYTES), (uint32_t)(a4::V_BASE + ((1 + 1) % 3) * TILE_BYTES));
       }
-      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
-    { constexpr int R = 2; CA_A4_T(ts0); dma_prepare(t + 3, 2, false); dma_prepare(t + 1, 0, true); CA_A4_T(ts1);
+      CA_A4_ADVANCE(); CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
+    { constexpr int R = 2; (void)R; CA_A4_T(ts0); CA_A4_BOOKKEEPING(2); CA_A4_T(ts1);
       if (active) {
 #define CA_A4_SCHEDULE
 #include "ca_attn4_sched.inc"
 #undef CA_A4_SCHEDULE
-      } else {
-        stage_pieces();
+      } else {   // a wave whose query rows do not exist: its share of the staging only
+        stage_pieces((uint32_t)(2 * TILE_BYTES), (uint32_t)(a4::V_BASE + ((2 + 1) % 3) * TILE_BYTES));
       }
-      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
+      CA_A4_ADVANCE(); CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
   }
   if (t < T) {   // (t % 3 == 0 here) one or two iterations left
-    { constexpr int R = 0; CA_A4_T(ts0); dma_prepare(t + 3, 0, false); dma_prepare(t + 1, 1, true); CA_A4_T(ts1);
+    { constexpr int R = 0; (void)R; CA_A4_T(ts0); CA_A4_BOOKKEEPING(0); CA_A4_T(ts1);
       if (active) {
 #define CA_A4_SCHEDULE
 #include "ca_attn4_sched.inc"
 #undef CA_A4_SCHEDULE
-      } else {
-        stage_pieces();
+      } else {   // a wave whose query rows do not exist: its share of the staging only
+        stage_pieces((uint32_t)(0 * TILE_BYTES), (uint32_t)(a4::V_BASE + ((0 + 1) % 3) * TILE_BYTES));
       }
-      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
-    if (t < T) {
-      constexpr int R = 1; CA_A4_T(ts0); dma_prepare(t + 3, 1, false); dma_prepare(t + 1, 2, true); CA_A4_T(ts1);
+      CA_A4_ADVANCE(); CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
+    if (t < T) { constexpr int R = 1; (void)R; CA_A4_T(ts0); CA_A4_BOOKKEEPING(1); CA_A4_T(ts1);
       if (active) {
 #define CA_A4_SCHEDULE
 #include "ca_attn4_sched.inc"
 #undef CA_A4_SCHEDULE
-      } else {
-        stage_pieces();
+      } else {   // a wave whose query rows do not exist: its share of the staging only
+        stage_pieces((uint32_t)(1 * TILE_BYTES), (uint32_t)(a4::V_BASE + ((1 + 1) % 3) * TILE_BYTES));
       }
-      CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
+      CA_A4_ADVANCE(); CA_A4_T(ts2); drain_and_barrier(); CA_A4_T(ts3); CA_A4_ACC(); ++t; }
   }
 #ifdef CA_A4_STAMP
   if (lane == 0 && blockIdx.x < 4096) {
@@ -406,9 +412,10 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(S00), "+v"(S01), "+v"(S10), "+v"(S11));
     // finish_pending: what the next iteration would have done in its first gaps (see the first tile above)
     {
-      float r1 = S11[4] + S11[5];
+      l0 += S10[14] + S10[15];
+      float r1 = 0.f;
 #pragma unroll
-      for (int r = 6; r < 16; ++r) {
+      for (int r = 0; r < 16; ++r) {
         S11[r] = __builtin_amdgcn_exp2f(S11[r]);
         r1 += S11[r];
       }

@@ -26,7 +26,10 @@ live in VGPRs, O in AGPRs.
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "conceptattention_amd", "csrc", "ca_attn4_sched.inc")
+OUT = os.environ.get("CA_A4_OUT") or os.path.join(ROOT, "conceptattention_amd", "csrc", "ca_attn4_sched.inc")
+# timing-only knock-outs (tools/attn4_knockouts.py; the results of such a build are wrong): a comma list of
+#   nop4 (s_nop 0 in place of the SGPR->VMEM s_nop 4), exp (v_mov for v_exp), add, cvt, lds (no LDS reads / waits), dma
+KO = set(filter(None, os.environ.get("CA_A4_KO", "").split(",")))
 
 AO, AQ, AK, AV = 0, 128, 192, 224
 TILE = 16384
@@ -82,12 +85,18 @@ class Stream:
         self.lines.append(f"    // {c}")
 
     def read_k(self, ring, off, ks, name):
+        if "lds" in KO:
+            self.tag[name] = self.lds
+            return
         self.ins(f"ds_read_b128 {areg(AK + 4 * ring, 4)}, {{0}} offset:{off}", (f"ka{ks}", "r"))
         self.lds += 1
         self.tag[name] = self.lds
 
     def read_v(self, ring, vslot_off, kb, sk, db, name):
         row = (32 * kb + 16 * sk) * 256
+        if "lds" in KO:
+            self.tag[name] = self.lds
+            return
         self.ins(f"ds_read_b64_tr_b16 {areg(AV + 4 * ring, 2)}, {{0}} offset:{vslot_off + row}", (f"va0{db}", "r"))
         self.ins(f"ds_read_b64_tr_b16 {areg(AV + 4 * ring + 2, 2)}, {{0}} offset:{vslot_off + row + 2048}",
                  (f"va1{db}", "r"))
@@ -96,6 +105,8 @@ class Stream:
 
     def wait_for(self, name):
         assert name in self.tag, f"{name} waited for before it was issued"
+        if "lds" in KO:
+            return
         self.ins(f"s_waitcnt lgkmcnt({min(self.lds - self.tag[name], 15)})")   # the counter field has 4 bits
 
 
@@ -104,71 +115,88 @@ def S(kb, qb):
 
 
 def gen_iteration(r):
-    """Iteration t with t % 3 == r: K(t+1) in K slot (r+1)%3, K(t+2) in (r+2)%3, V(t) in V slot r."""
+    """Iteration t with t % 3 == r: K(t+1) in K slot (r+1)%3, K(t+2) in (r+2)%3, V(t) in V slot r; the LDS-DMA of this
+    iteration fills K slot r with K(t+3) and V slot (r+1)%3 with V(t+1).
+
+    MFMA slots: 0..31 S(t+1) = K(t+1) Q^T with the two query blocks' chains INTERLEAVED (slot s: key block s>>4, K
+    fragment (s>>1)&7, query block s&1 -- a chain's MFMAs are two slots apart, so none waits for its predecessor's
+    result; back to back they cost 3.75 cycles each), 32..63 O^T += V(t)^T P(t)^T (fragment (s-32)>>1, query block s&1).
+    """
     k1, k2, v0 = ((r + 1) % 3) * TILE, ((r + 2) % 3) * TILE, r * TILE
+    kdst, vdst = r * TILE, 3 * TILE + ((r + 1) % 3) * TILE     # LDS byte offsets of the DMA destinations (wave part added
+                                                               # through LWK / LWV)
     st = Stream()
-    # ---- the exponentials: ONE per MFMA gap, 64 gaps for the tile's 64 scores per lane.  Order S00, S01, S10, S11
-    # starting at slot 10 (a block is exponentiated >= 2 MFMA slots after the MFMA that completes it: S00 at slot 7,
-    # S01 at 15, S10 at 23, S11 at 31); the last ten (S11[6..15]) wrap into slots 0..9 of the NEXT iteration -- S11 is
-    # not written again before slot 24.  So at the top of an iteration S11 still holds the previous pass's raw
-    # (score - reference) values in elements 6..15, and P110 / P111 are not packed yet: ca_attn4.hip hands the loop
-    # exactly that state and completes it after the loop (CA_A4 "pending S11" in the kernel).
-    order = []
-    n = 10
-    for kb, qb in ((0, 0), (0, 1), (1, 0), (1, 1)):
-        for i in range(16):
-            order.append((n, kb, qb, i))
-            n += 1
+    # ---- the exponentials: ONE per MFMA gap.  S(kb, qb) is complete after slot 14 + qb + 16 kb; its 16 values are
+    # exponentiated in the 16 gaps that start two slots later: S00 in gaps 16..31, S01 32..47, S10 48..63, S11 64..79 =
+    # gaps 0..15 of the NEXT iteration (S11 is not written again before slot 17).  So at the top of an iteration S11
+    # still holds the previous pass's raw (score - reference) values and P101 / P110 / P111 are not packed yet:
+    # ca_attn4.hip hands the loop exactly that state and completes it after the loop ("pending" in the kernel).
+    order = [(kb, qb, i) for kb, qb in ((0, 0), (0, 1), (1, 0), (1, 1)) for i in range(16)]
     # hipcc gives every statement AT MOST ONE written element per vector variable for free (a second tied or defined
     # sub-register of the same tuple costs it a copy out and back), and pads an s_nop behind a statement whose output the
     # NEXT statement reads.  So one exponential per statement, and the row-sum add of a value rides two exponentials
     # later (also >= the one wait state a transcendental needs), into two accumulators per query block in turn
     # (l0 / l0b, l1 / l1b): consecutive statements then never read each other's output.
-    exps_of = {s: [] for s in range(64)}
-    for n, (slot, kb, qb, i) in enumerate(order):
-        add = order[n - 2][1:] + ("" if n % 2 == 0 else "b",)      # (n < 2: the previous pass's last two values)
-        exps_of[slot % 64].append(((kb, qb, i), add))
-    WRAP_FIRST = 64 - 10     # order[54:] are issued at slots 0..9 of the next iteration
-    # ---- packs: P[kb][qb][sk] dword j <- (S[kb][qb][8sk+2j], S[kb][qb][8sk+2j+1]); after the values' exponentials and
-    # after the last P.V MFMA of tile t that reads P[kb][qb][sk] (slot 32 + 2*(kb*8+sk*4+3) + qb); at most one pack per
-    # vector variable and statement.
-    cvt_of = {s: [] for s in range(64)}
+    exps_of = {}
+    for n, e in enumerate(order):
+        a = order[(n - 2) % 64]
+        exps_of[(16 + n) % 64] = (e, a + ("" if n % 2 == 0 else "b",))
+    # ---- packs: P[kb][qb][sk] dword j <- (S[kb][qb][8sk+2j], S[kb][qb][8sk+2j+1]); after the values' exponentials (at
+    # least one gap later) and after the last P.V MFMA of tile t that reads P[kb][qb][sk] (slots 32 + 16 kb + 8 sk ..+7);
+    # at most one pack per vector variable and statement; on gaps without V reads where there is a choice.
+    cvt_of = {s_: [] for s_ in range(64)}
     def cvts(slots, kb, qb, sk):
         for j, s_ in enumerate(slots):
             cvt_of[s_ % 64].append((kb, qb, sk, j))
-    cvts([40, 41, 42, 43], 0, 0, 0)    # S00[0..7]  exponentiated by slot 17; P000 last read at slot 38
-    cvts([40, 41, 42, 43], 0, 1, 0)    # S01[0..7]  by slot 33;              P010 at 39
-    cvts([48, 49, 50, 51], 0, 0, 1)    # S00[8..15] by 25;                   P001 at 46
-    cvts([48, 49, 50, 51], 0, 1, 1)    # S01[8..15] by 41;                   P011 at 47
-    cvts([56, 57, 58, 59], 1, 0, 0)    # S10[0..7]  by 49;                   P100 at 54
-    cvts([64, 65, 70, 71], 1, 0, 1)    # S10[8..15] by 57;                   P101 last read at slot 62 -> next iteration
-    cvts([66, 67, 68, 69], 1, 1, 0)    # S11[0..7]  by 65 (= slot 1 of the next iteration); P110 last read at slot 55
-    cvts([76, 77, 78, 79], 1, 1, 1)    # S11[8..15] by 73;                   P111 at 63
-    reads = {s: [] for s in range(64)}
+    cvts([40, 42, 44, 46], 0, 0, 0)    # S00[0..7]  exponentiated by gap 23; P000 last read at slot 38
+    cvts([40, 42, 44, 46], 0, 1, 0)    # S01[0..7]  by 39;                   P010 at 39
+    cvts([48, 50, 52, 54], 0, 0, 1)    # S00[8..15] by 31;                   P001 at 46
+    cvts([48, 50, 52, 54], 0, 1, 1)    # S01[8..15] by 47;                   P011 at 47
+    cvts([56, 57, 58, 59], 1, 0, 0)    # S10[0..7]  by 55;                   P100 at 54
+    cvts([64, 65, 66, 67], 1, 0, 1)    # S10[8..15] by 63;                   P101 at 62 -> gaps 0..3 of the next iteration
+    cvts([72, 73, 74, 75], 1, 1, 0)    # S11[0..7]  by 71;                   P110 at 55 -> gaps 8..11
+    cvts([74, 76, 78, 80], 1, 1, 1)    # S11[8..15]: pair j by 73 + 2j;      P111 at 63 -> gaps 10, 12, 14, 16 (the S11
+                                       # chain restarts at slot 17)
+    # ---- LDS reads (the LDS returns data in order: a counted wait names the reads issued after the one needed)
+    reads = {s_: [] for s_ in range(64)}
     for ks in range(8):
-        reads[9 + ks].append(("k", ks, k1 + 8192, ks, f"k1_{ks}"))        # K(t+1) key block 1, fragment ks -> ring ks
-    for f in range(8):
+        reads[2 + 2 * ks].append(("k", ks, k1 + 8192, ks, f"k1_{ks}"))   # K(t+1) key block 1: ring entry ks is free after
+                                                                         # slot 2 ks + 1, needed at slot 16 + 2 ks
+        reads[18 + 2 * ks].append(("k", ks, k2, ks, f"k2_{ks}"))         # K(t+2) key block 0 (for the NEXT iteration; no
+                                                                         # tile t+2: a stale slot is read, unused)
+    for f in range(16):
         kb, sk, db = f >> 3, (f >> 2) & 1, f & 3
-        reads[17 + f].append(("v", f, v0, kb, sk, db, f"v_{f}"))          # V(t) fragments 0..7
-    for ks in range(8):
-        reads[25 + ks].append(("k", ks, k2, ks, f"k2_{ks}"))              # K(t+2) key block 0 (for the NEXT iteration;
-                                                                          # no tile t+2: a stale slot is read, unused)
-    for f in range(8, 16):
-        kb, sk, db = f >> 3, (f >> 2) & 1, f & 3
-        reads[34 + 2 * (f - 8)].append(("v", f - 8, v0, kb, sk, db, f"v_{f}"))
+        g = 17 + 2 * f if f < 8 else 35 + 2 * (f - 8)     # V(t) fragment f -> ring entry f & 7 (free after slot 17 + 2 f)
+        reads[g].append(("v", f & 7, v0, kb, sk, db, f"v_{f}"))
+    waits = {16: "k1_3", 24: "k1_7", 32: "v_3", 40: "v_7", 48: "v_11", 56: "v_15"}
+    # ---- LDS-DMA: this wave's 4 + 4 pieces (1 KiB each) of K(t+3) / V(t+1) in the odd gaps 1..15 (the even ones carry
+    # the K reads): buffer_load ... lds with M0 = the piece's LDS address, a buffer descriptor per matrix (DSK / DSV: the
+    # key segment's base, so that byte offset = key index x row bytes in both segments), the tile's byte offset as the
+    # scalar offset (SOK / SOV) and the lane's offset inside the tile (koff / voff).  For a tile that does not exist, or
+    # that ca_attn4.hip stages the general way, the descriptor is the null one (0 records: nothing is read) and LWK / LWV
+    # point into the dump page.  hipcc itself never uses M0 in this kernel (build.py checks it), so it is neither
+    # saved nor restored.  SGPR hazards (an SGPR written by SALU / v_readlane needs 5 wait states before a VMEM
+    # instruction reads it; M0 one state before the LDS-DMA): the M0 write sits in front of the MFMA, and build.py audits
+    # the emitted code for writes of the descriptor / offset registers within 5 instructions of a piece.
+    dma_of = {1 + 2 * i: (i >> 1, i & 1) for i in range(8)}       # gap -> (piece j, is_v): K0 V0 K1 V1 ...
 
     def exp_and_add(e):
         (kb, qb, i), add = e
-        st.ins("v_exp_f32 {0}, {0}", (f"{S(kb, qb)}[{i}]", "rw"))
+        st.ins(("v_mov_b32 {0}, {0}" if "exp" in KO else "v_exp_f32 {0}, {0}"), (f"{S(kb, qb)}[{i}]", "rw"))
         akb, aqb, ai, sfx = add
-        st.ins("v_add_f32 {0}, {0}, {1}", (f"l{aqb}{sfx}", "rw"), (f"{S(akb, aqb)}[{ai}]", "r"))
+        if "add" not in KO:
+            st.ins("v_add_f32 {0}, {0}, {1}", (f"l{aqb}{sfx}", "rw"), (f"{S(akb, aqb)}[{ai}]", "r"))
 
     st.comment(f"---- iteration variant r = {r}: K(t+1) slot {(r + 1) % 3}, K(t+2) slot {(r + 2) % 3}, V(t) slot {r}")
     for s in range(64):
+        dma = dma_of.get(s) if "dma" not in KO else None
+        if dma:
+            j, isv = dma
+            st.ins(f"s_add_u32 m0, {{0}}, {(vdst if isv else kdst) + 1024 * j}", ("LWV" if isv else "LWK", "rs"))
+        if s in waits:
+            st.wait_for(waits[s])
         if s < 32:
-            kb, qb, ks = s >> 4, (s >> 3) & 1, s & 7
-            if kb == 1 and qb == 0 and ks % 2 == 0:
-                st.wait_for(f"k1_{ks + 1}")     # one wait per two fragments
+            kb, ks, qb = s >> 4, (s >> 1) & 7, s & 1
             a = areg(AK + 4 * ks, 4)
             q = areg(AQ + 4 * (qb * 8 + ks), 4)
             if ks == 0:
@@ -178,49 +206,65 @@ def gen_iteration(r):
         else:
             f, qb = (s - 32) >> 1, (s - 32) & 1
             kb, sk, db = f >> 3, (f >> 2) & 1, f & 3
-            if qb == 0 and f % 2 == 0:
-                st.wait_for(f"v_{f + 1}")       # one wait per two fragments
             o = areg(AO + 16 * (qb * 4 + db), 16)
             v = areg(AV + 4 * (f & 7), 4)
             st.ins(f"v_mfma_f32_32x32x16_bf16 {o}, {v}, {{0}}, {o}", (f"P{kb}{qb}{sk}", "r"))
-        if s < 8:
-            # LDS-DMA of this wave's 4 + 4 pieces (1 KiB each) of K(t+3) / V(t+1), one per gap: scalar tile base + lane
-            # offset, M0 = the piece's LDS address.  (hipcc itself never uses M0 in this kernel: build.py checks that,
-            # so it is neither saved nor restored.)  DMAK / DMAV are 64-bit tile bases, LDK / LDV the LDS address of the
-            # wave's first piece; for a tile that does not exist, or that ca_attn4.hip staged the general way, they
-            # point at a valid tile and at the dump page, so no branch is needed here.
-            j, isv = s >> 1, s & 1
-            if os.environ.get("CA_A4_GEN_SKIP"):     # bisecting aid: skip the piece when the base is 0
-                st.ins("s_cmp_eq_u64 {0}, 0", ("DMAV" if isv else "DMAK", "rs"))
-                st.ins("s_cbranch_scc1 .Lca4_nodma%=")
-            st.ins(f"s_add_u32 m0, {{0}}, {1024 * j}", ("LDV" if isv else "LDK", "rs"))
-            # M0 write -> LDS-DMA: one wait state.  And the tile base: an SGPR written by SALU or VALU needs 5 wait
-            # states before a VMEM instruction may use it as its address; hipcc pads nothing inside an asm statement and
-            # may write the pair right in front of ANY of these statements (scalar bookkeeping in front of the first
-            # piece, a v_readlane reload of a spilled SGPR in front of any other).  With one state here the pieces
-            # intermittently read through a half-updated base (address 0xffff....: a fault that came and went).
-            st.ins("s_nop 4")
-            st.ins("global_load_lds_dwordx4 {0}, {1}", (f"{'voff' if isv else 'koff'}{j}", "r"),
-                   ("DMAV" if isv else "DMAK", "rs"))
-            if os.environ.get("CA_A4_GEN_SKIP"):
-                st.ins(".Lca4_nodma%=:")
+        if dma:
+            j, isv = dma
+            st.ins("buffer_load_dwordx4 {0}, {1}, {2} offen lds", (f"{'voff' if isv else 'koff'}{j}", "r"),
+                   ("DSV" if isv else "DSK", "rs"), ("SOV" if isv else "SOK", "rs"))
         for rd in reads[s]:
             if rd[0] == "k":
                 st.read_k(rd[1], rd[2], rd[3], rd[4])
             else:
                 st.read_v(rd[1], rd[2], rd[3], rd[4], rd[5], rd[6])
-        st.flush()      # statement A: wait, MFMA, LDS reads, DMA.  Statement B: the VALU fillers -- with a statement
+        st.flush()      # statement A: M0, wait, MFMA, DMA, LDS reads.  Statement B: the VALU fillers -- with a statement
                         # between two MFMAs of one accumulation chain hipcc has no reason to pad an s_nop between them
         seen = set()
         for (kb, qb, sk, j) in cvt_of[s]:
             assert (kb, qb, sk) not in seen        # one written element per vector variable and statement
             seen.add((kb, qb, sk))
+            if "cvt" in KO:
+                continue
             st.ins("v_cvt_pk_bf16_f32 {0}, {1}, {2}", (f"P{kb}{qb}{sk}[{j}]", "w"),
                    (f"{S(kb, qb)}[{8 * sk + 2 * j}]", "r"), (f"{S(kb, qb)}[{8 * sk + 2 * j + 1}]", "r"))
-        assert len(exps_of[s]) == 1
-        exp_and_add(exps_of[s][0])
+        exp_and_add(exps_of[s])
         st.flush()
+    check_schedule(exps_of, cvt_of, reads, waits)
     return st.lines
+
+
+def check_schedule(exps_of, cvt_of, reads, waits):
+    """The placement rules of the stream, asserted (gap g = the instructions behind MFMA slot g; gaps of the next
+    iteration count 64 + g).  Times are in slots; an MFMA issued in slot s has written its result before gap s + 2."""
+    done_at = lambda kb, qb: 14 + qb + 16 * kb                      # slot of the chain's last MFMA
+    exp_gap = {}
+    for g, ((kb, qb, i), _) in exps_of.items():
+        first_write = 16 * kb + qb                                   # slot of the chain's first MFMA
+        gg = g if g >= done_at(kb, qb) + 2 else g + 64               # this iteration, or lapped into the next one
+        assert gg >= done_at(kb, qb) + 2 and gg < 64 + first_write, (kb, qb, i, g)
+        exp_gap[(kb, qb, i)] = gg
+    for g, lst in cvt_of.items():
+        for (kb, qb, sk, j) in lst:
+            last_read = 32 + 16 * kb + 8 * sk + 6 + qb               # last P.V MFMA of tile t reading P[kb][qb][sk]
+            e = max(exp_gap[(kb, qb, 8 * sk + 2 * j)], exp_gap[(kb, qb, 8 * sk + 2 * j + 1)])
+            gg = g if (g > last_read and g > e) else g + 64
+            assert gg > last_read and gg > e, ("pack before its exponentials / its last reader", kb, qb, sk, j, g)
+            assert gg < 64 + 16 * kb + qb or gg - 64 < 16 * kb + qb + 1, ("pack after the chain restarted", kb, qb, sk, j)
+            assert gg < 64 + 32 + 16 * kb + 8 * sk, ("pack after its first reader of the next tile", kb, qb, sk, j)
+    for g, lst in reads.items():
+        for rd in lst:
+            if rd[0] == "k":
+                ks, name = rd[1], rd[4]
+                if name.startswith("k1_"):       # overwrites K(t+1) kb 0 fragment ks (last read slot 2ks+1), used at 16+2ks
+                    assert g > 2 * ks + 1 and g + 6 <= 16 + 2 * ks, name
+                else:                            # overwrites kb 1 fragment ks (last read slot 17+2ks), used at 64+2ks
+                    assert g > 17 + 2 * ks, name
+            else:
+                f = int(rd[6].split("_")[1])
+                assert g + 6 <= 32 + 2 * f, rd[6]
+                if f >= 8:
+                    assert g > 33 + 2 * (f - 8), rd[6]   # ring entry f & 7 held fragment f - 8
 
 
 def gen_helpers():

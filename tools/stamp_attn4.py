@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "conceptattention_amd", "csrc")
-LIB = os.path.join(ROOT, "tools", "ab_libs", "libca_a4_stamp.so")
+LIB = os.environ.get("CA_A4_STAMP_LIB") or os.path.join(ROOT, "tools", "ab_libs", "libca_a4_stamp.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
