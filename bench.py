@@ -425,7 +425,10 @@ def main():
         if attn_records:   # second MFMA kernel of the path, timed the same way on the same solo step
             fl = sum(r[0] for r in attn_records)
             sec = sum(r[1].elapsed_time(r[2]) for r in attn_records) * 1e-3
-            roof_attn = {"bound": "mfma", "kernel": "ca_attn_kernel<8> (256 query rows x 64-key tiles)",
+            attn_kernel = ("ca_attn_kernel<8> (two waves per SIMD, 256 query rows x 64-key tiles)"
+                           if os.environ.get("CA_ATTN_KERNEL") == "8" else
+                           "ca_attn4_kernel (one wave per SIMD, 4 x 64 query rows x 64-key tiles, generated stream)")
+            roof_attn = {"bound": "mfma", "kernel": attn_kernel,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": len(attn_records),
                          "avg_launch_us": sec / len(attn_records) * 1e6, "flops_per_launch": fl / len(attn_records),
                          "achieved": fl / sec / 1e12, "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
@@ -445,8 +448,9 @@ def main():
                 roof["traffic_source"] = (f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                           f"passes of this command at {pmc_doc.get('git_head', 'an earlier commit')}; "
                                           "counters cannot be read from inside the process)")
-            if roof_attn is not None and "ca_attn_kernel<8>" in pmc and not fp8:
-                roof_attn["traffic"] = pmc["ca_attn_kernel<8>"]["bytes_per_launch"]
+            akey = roof_attn["kernel"].split(" ")[0] if roof_attn is not None else None
+            if akey in pmc and not fp8:
+                roof_attn["traffic"] = pmc[akey]["bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         roof["frac"] = roof["achieved"] / roof["peak"]

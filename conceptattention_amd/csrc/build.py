@@ -65,6 +65,14 @@ def audit_sgpr_hazards(text: str) -> list:
             out |= set(range(int(a), int(b) + 1))
         out |= {int(x) for x in re.findall(r"\bs(\d+)\b", tok)}
         return out
+    def vregs(tok):
+        out = set()
+        for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", tok):
+            out |= set(range(int(a), int(b) + 1))
+        out |= {int(x) for x in re.findall(r"\bv(\d+)\b", tok)}
+        return out
+    vhist = []                             # (wait states, VALU-written VGPRs, text): a VGPR written by a VALU instruction
+                                           # needs 2 wait states before an MFMA reads it as A / B / C
     hist, bad, inside = [], [], False      # hist: (wait states, VALU-written SGPRs, writes M0, text)
     for line in text.split("\n"):
         code = line.split(";")[0].strip()
@@ -88,7 +96,19 @@ def audit_sgpr_hazards(text: str) -> list:
                 if wm0 and states < 1 and " lds" in code + " ":
                     bad.append(f"{txt} -> {code} (M0, {states} wait states)")
                 states += ws
+        if inside and op.startswith("v_mfma"):
+            need, states = vregs(",".join(args.split(",")[1:])), 0
+            for ws_, written, txt in reversed(vhist):
+                if states >= 2:
+                    break
+                if written & need:
+                    bad.append(f"{txt} -> {code} ({states} wait states)")
+                states += ws_
         ws = int(args.split()[0], 0) + 1 if op == "s_nop" else 1
+        is_valu = op.startswith("v_") and not op.startswith(("v_mfma", "v_accvgpr_write", "v_cmp", "v_readlane",
+                                                              "v_readfirstlane"))
+        vhist.append((ws, vregs(args.split(",")[0]) if is_valu else set(), code))
+        vhist = vhist[-6:]
         first = args.split(",")[0]
         valu_sgpr_write = sregs(first) if op.startswith("v_") else set()
         if op.startswith("v_cmp") and "_e64" not in op and "s" not in first:

@@ -137,10 +137,15 @@ def gen_iteration(r):
     # NEXT statement reads.  So one exponential per statement, and the row-sum add of a value rides two exponentials
     # later (also >= the one wait state a transcendental needs), into two accumulators per query block in turn
     # (l0 / l0b, l1 / l1b): consecutive statements then never read each other's output.
-    exps_of = {}
+    exps_of, adds_of = {}, {g: [] for g in range(64)}
     for n, e in enumerate(order):
         a = order[(n - 2) % 64]
-        exps_of[(16 + n) % 64] = (e, a + ("" if n % 2 == 0 else "b",))
+        g = (16 + n) % 64
+        exps_of[g] = e
+        # (the last value of S11 is added one gap early, together with its predecessor: the S11 chain restarts at slot
+        # 17, and an add in gap 17 would read S11[15] while that MFMA is in flight -- correct only as long as nothing
+        # delays the add past the MFMA's write-back: a result that came and went with the LDS queue's state)
+        adds_of[g - 1 if a == (1, 1, 15) else g].append(a + ("" if n % 2 == 0 else "b",))
     # ---- packs: P[kb][qb][sk] dword j <- (S[kb][qb][8sk+2j], S[kb][qb][8sk+2j+1]); after the values' exponentials (at
     # least one gap later) and after the last P.V MFMA of tile t that reads P[kb][qb][sk] (slots 32 + 16 kb + 8 sk ..+7);
     # at most one pack per vector variable and statement; on gaps without V reads where there is a choice.
@@ -180,12 +185,12 @@ def gen_iteration(r):
     # the emitted code for writes of the descriptor / offset registers within 5 instructions of a piece.
     dma_of = {1 + 2 * i: (i >> 1, i & 1) for i in range(8)}       # gap -> (piece j, is_v): K0 V0 K1 V1 ...
 
-    def exp_and_add(e):
-        (kb, qb, i), add = e
+    def exp_and_add(g):
+        kb, qb, i = exps_of[g]
         st.ins(("v_mov_b32 {0}, {0}" if "exp" in KO else "v_exp_f32 {0}, {0}"), (f"{S(kb, qb)}[{i}]", "rw"))
-        akb, aqb, ai, sfx = add
-        if "add" not in KO:
-            st.ins("v_add_f32 {0}, {0}, {1}", (f"l{aqb}{sfx}", "rw"), (f"{S(akb, aqb)}[{ai}]", "r"))
+        for akb, aqb, ai, sfx in adds_of[g]:
+            if "add" not in KO:
+                st.ins("v_add_f32 {0}, {0}, {1}", (f"l{aqb}{sfx}", "rw"), (f"{S(akb, aqb)}[{ai}]", "r"))
 
     st.comment(f"---- iteration variant r = {r}: K(t+1) slot {(r + 1) % 3}, K(t+2) slot {(r + 2) % 3}, V(t) slot {r}")
     for s in range(64):
@@ -228,29 +233,34 @@ def gen_iteration(r):
                 continue
             st.ins("v_cvt_pk_bf16_f32 {0}, {1}, {2}", (f"P{kb}{qb}{sk}[{j}]", "w"),
                    (f"{S(kb, qb)}[{8 * sk + 2 * j}]", "r"), (f"{S(kb, qb)}[{8 * sk + 2 * j + 1}]", "r"))
-        exp_and_add(exps_of[s])
+        exp_and_add(s)
         st.flush()
-    check_schedule(exps_of, cvt_of, reads, waits)
+    check_schedule(exps_of, adds_of, cvt_of, reads, waits)
     return st.lines
 
 
-def check_schedule(exps_of, cvt_of, reads, waits):
+def check_schedule(exps_of, adds_of, cvt_of, reads, waits):
     """The placement rules of the stream, asserted (gap g = the instructions behind MFMA slot g; gaps of the next
     iteration count 64 + g).  Times are in slots; an MFMA issued in slot s has written its result before gap s + 2."""
     done_at = lambda kb, qb: 14 + qb + 16 * kb                      # slot of the chain's last MFMA
     exp_gap = {}
-    for g, ((kb, qb, i), _) in exps_of.items():
+    for g, (kb, qb, i) in exps_of.items():
         first_write = 16 * kb + qb                                   # slot of the chain's first MFMA
         gg = g if g >= done_at(kb, qb) + 2 else g + 64               # this iteration, or lapped into the next one
         assert gg >= done_at(kb, qb) + 2 and gg < 64 + first_write, (kb, qb, i, g)
         exp_gap[(kb, qb, i)] = gg
+    for g, lst in adds_of.items():
+        for (kb, qb, i, _) in lst:       # after the value's exponential (>= 1 gap), before the chain's next first MFMA
+            e = exp_gap[(kb, qb, i)]
+            gg = g if g > e else g + 64
+            assert e < gg < 64 + 16 * kb + qb, ("row-sum add outside its value's life", kb, qb, i, g)
     for g, lst in cvt_of.items():
         for (kb, qb, sk, j) in lst:
             last_read = 32 + 16 * kb + 8 * sk + 6 + qb               # last P.V MFMA of tile t reading P[kb][qb][sk]
             e = max(exp_gap[(kb, qb, 8 * sk + 2 * j)], exp_gap[(kb, qb, 8 * sk + 2 * j + 1)])
             gg = g if (g > last_read and g > e) else g + 64
             assert gg > last_read and gg > e, ("pack before its exponentials / its last reader", kb, qb, sk, j, g)
-            assert gg < 64 + 16 * kb + qb or gg - 64 < 16 * kb + qb + 1, ("pack after the chain restarted", kb, qb, sk, j)
+            assert gg < 64 + 16 * kb + qb, ("pack after the chain restarted", kb, qb, sk, j)
             assert gg < 64 + 32 + 16 * kb + 8 * sk, ("pack after its first reader of the next tile", kb, qb, sk, j)
     for g, lst in reads.items():
         for rd in lst:
@@ -294,7 +304,7 @@ def gen_helpers():
         L.append("  } while (0)")
         L.append("")
     # ---- O *= alpha (safe path only): al0 / al1 per query block
-    L.append("#define CA_A4_SCALE_O(al0, al1) do { float t_; asm volatile(\"s_nop 15\\n\\ts_nop 7\"); \\")
+    L.append("#define CA_A4_SCALE_O(al0, al1) do { float t_; asm volatile(\"s_nop 15\\n\\ts_nop 7\" : : \"v\"(al0), \"v\"(al1)); \\")
     for qb in range(2):
         for i in range(64):
             a = AO + 64 * qb + i
@@ -328,7 +338,11 @@ def gen_helpers():
         L.append('  asm volatile("s_nop 15\\n\\ts_nop 7" : "+v"(S00), "+v"(S01), "+v"(S10), "+v"(S11)); } while (0)')
         L.append("")
     # ---- plain O^T += V^T P^T of one tile: vbase = V slot byte offset (runtime)
-    L.append("#define CA_A4_PV_PLAIN(vbase) do { asm volatile(\"s_nop 7\"); \\")
+    # (its first statement takes every P fragment through an s_nop: hipcc pads no hazard INTO an asm statement, and a
+    # pack -- VALU write -- right in front of the MFMA that reads it as B needs 2 wait states; without the operands
+    # hipcc is free to sink the packs below a bare s_nop, and query block 0's first MFMA then read stale registers)
+    allp = ", ".join(f'"+v"(P{kb}{qb}{sk})' for kb in range(2) for qb in range(2) for sk in range(2))
+    L.append(f"#define CA_A4_PV_PLAIN(vbase) do {{ asm volatile(\"s_nop 7\" : {allp}); \\")
     for f in range(16):
         kb, sk, db = f >> 3, (f >> 2) & 1, f & 3
         row = (32 * kb + 16 * sk) * 256

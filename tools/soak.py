@@ -27,10 +27,13 @@ def attn():
     return o
 
 
+q4 = (q.float() * (1.4426950408889634 / 128 ** 0.5)).bfloat16()
+
+
 def attn4():
     o = torch.zeros(C + n, 3072, device=dev, dtype=torch.bfloat16)
-    ops.attention([ops.Attn(q[C:], o[C:], k[C:], v[C:]), ops.Attn(q[:C], o[:C], k[:C], v[:C], k[C + 256:], v[C + 256:])], nh,
-                  q_prescaled=True)
+    ops.attention([ops.Attn(q4[C:], o[C:], k[C:], v[C:]), ops.Attn(q4[:C], o[:C], k[:C], v[:C], k[C + 256:], v[C + 256:])],
+                  nh, q_prescaled=True)
     return o
 
 
