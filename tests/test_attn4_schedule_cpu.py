@@ -1,0 +1,84 @@
+"""The generated instruction stream of ca_attn4_kernel and the audits that guard it (no GPU needed).
+
+* the committed conceptattention_amd/csrc/ca_attn4_sched.inc is what tools/gen_attn4_schedule.py generates (the generator
+  asserts its own placement rules while it runs: every exponential / row-sum add / pack inside the life of its score
+  value, every LDS read early enough and behind the last reader of the ring entry it overwrites);
+* csrc/build.py's audits flag the hazards hipcc does not pad inside asm statements -- each of them was a real bug of
+  round 3: a VALU-written SGPR read by an LDS-DMA piece too early, M0 written right in front of
+  its LDS-DMA, a VALU-written VGPR read by an MFMA within 2 wait states.
+"""
+import importlib.util
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "conceptattention_amd", "csrc", "ca_attn4_sched.inc")
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_committed_schedule_is_the_generated_one(tmp_path):
+    out = tmp_path / "sched.inc"
+    env = dict(os.environ, CA_A4_OUT=str(out))
+    env.pop("CA_A4_KO", None)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn4_schedule.py")], check=True, env=env,
+                   capture_output=True)
+    assert out.read_text() == open(INC).read(), "regenerate with: python tools/gen_attn4_schedule.py"
+
+
+def test_stream_shape():
+    """Per iteration variant: 64 MFMAs, 64 exponentials, 64 row-sum adds, 32 packs, 16 + 32 LDS fragment reads, 8 LDS-DMA
+    pieces with their 8 M0 writes, and only counted waits."""
+    text = open(INC).read()
+    sched = text[text.index("#ifdef CA_A4_SCHEDULE"):]
+    variants = sched.split("---- iteration variant")[1:]
+    assert len(variants) == 3
+    for v in variants:
+        assert v.count("v_mfma_f32_32x32x16_bf16") == 64
+        assert v.count("v_exp_f32") == 64 and v.count("v_add_f32") == 64 and v.count("v_cvt_pk_bf16_f32") == 32
+        assert v.count("ds_read_b128") == 16 and v.count("ds_read_b64_tr_b16") == 32
+        assert v.count("buffer_load_dwordx4") == 8 and v.count("s_add_u32 m0") == 8
+        assert "s_nop" not in v and "lgkmcnt(0)" in v and v.count("s_waitcnt") == 6
+
+
+def test_generator_rejects_a_misplaced_add():
+    """The rule that was violated in round 3: a row-sum add behind the slot in which its chain restarts."""
+    gen = _load(os.path.join(ROOT, "tools", "gen_attn4_schedule.py"), "gen_a4")
+    order = [(kb, qb, i) for kb, qb in ((0, 0), (0, 1), (1, 0), (1, 1)) for i in range(16)]
+    exps_of = {(16 + n) % 64: e for n, e in enumerate(order)}
+    adds_of = {g: [] for g in range(64)}
+    for n, e in enumerate(order):
+        adds_of[(16 + n) % 64].append(order[(n - 2) % 64] + ("",))      # S11[15] lands in gap 17: one gap too late
+    empty = {g: [] for g in range(64)}
+    try:
+        gen.check_schedule(exps_of, adds_of, empty, empty, {})
+    except AssertionError as e:
+        assert "row-sum add" in str(e.args[0])
+    else:
+        raise AssertionError("the misplaced add was accepted")
+
+
+def test_build_audits_flag_the_three_hazards():
+    build = _load(os.path.join(ROOT, "conceptattention_amd", "csrc", "build.py"), "ca_build")
+    ok = """\t;;#ASMSTART
+\ts_add_u32 m0, s1, 0
+\tv_mfma_f32_32x32x16_bf16 v[0:15], a[0:3], a[4:7], v[0:15]
+\tbuffer_load_dwordx4 v133, s[20:23], s31 offen lds
+\t;;#ASMEND
+"""
+    assert build.audit_sgpr_hazards(ok) == []
+    sgpr = "\tv_readlane_b32 s21, v180, 4\n\ts_add_u32 s5, s5, 1\n" + ok
+    assert any("v_readlane_b32 s21" in b for b in build.audit_sgpr_hazards(sgpr))
+    m0 = "\t;;#ASMSTART\n\ts_mov_b32 m0, s1\n\tbuffer_load_dwordx4 v133, s[40:43], s31 offen lds\n\t;;#ASMEND\n"
+    assert any("M0" in b for b in build.audit_sgpr_hazards(m0))
+    valu = ("\tv_cvt_pk_bf16_f32 v5, v21, v83\n\t;;#ASMSTART\n"
+            "\tv_mfma_f32_32x32x16_bf16 a[0:15], a[224:227], v[2:5], a[0:15]\n\t;;#ASMEND\n")
+    assert any("v_cvt_pk_bf16_f32 v5" in b for b in build.audit_sgpr_hazards(valu))
+    far = valu.replace("\t;;#ASMSTART", "\ts_nop 1\n\t;;#ASMSTART")
+    assert build.audit_sgpr_hazards(far) == []
