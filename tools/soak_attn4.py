@@ -28,6 +28,7 @@ for it in range(iters):
         qkv = (torch.randn(n, 3 * H, device=dev, generator=g) * (1.0 + 0.5 * (it % 3))).bfloat16()
         qkv[:, :H] = (qkv[:, :H].float() * sl2).bfloat16()
         first = None
+        torch.cuda.synchronize()      # the data is written on the default stream, the launches run on s1 / s2
     qs, ks, vs = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
     with torch.cuda.stream(s1 if it % 2 == 0 else s2):
         att = torch.zeros(n, H, device=dev, dtype=torch.bfloat16)
