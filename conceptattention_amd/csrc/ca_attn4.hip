@@ -89,23 +89,6 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
 
   asm volatile("" ::: CA_A4_AGPR_CLOBBERS);   // the AGPR file is ours: makes the kernel descriptor allocate it
 
-  // ---- Q fragments of both query blocks -> AGPRs
-  {
-    uint32_t qw[2][8][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int qrow = min(qrow0 + 32 * b + ql, nq - 1);
-      const bf16 *qp = (qrow < nq0 ? q_a + (size_t)qrow * ldq : q_b + (size_t)(qrow - nq0) * ldq) + head * 128 + h * 8;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const uint4 v = *(const uint4 *)(qp + ks * 16);
-        qw[b][ks][0] = v.x, qw[b][ks][1] = v.y, qw[b][ks][2] = v.z, qw[b][ks][3] = v.w;
-      }
-    }
-    CA_A4_WRITE_Q(qw);
-  }
-  CA_A4_ZERO_O();
-
   // ---- staging (LDS-DMA), 4 pieces of 1 KiB per wave and matrix; same images and source swizzles as ca_attn_kernel
   const int st_row = lane >> 4, st_cp = lane & 15;
   const bf16 *k0p = (const bf16 *)P.k0 + head * 128, *v0p = (const bf16 *)P.v0 + head * 128;
@@ -282,11 +265,28 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
     asm volatile("s_nop 7" : "+v"(NM0), "+v"(NM1));   // VALU write -> MFMA C operand (the asm MFMAs are opaque to hipcc)
   };
 
-  // ---- prologue: K(0), V(0), K(1), K(2)
+  // ---- prologue: K(0), V(0), K(1), K(2) are requested first, the Q rows behind them (one memory round trip for both)
   stage(0, 0, false);
   stage(0, 0, true);
   if (nt > 1) stage(1, 1, false);
   if (nt > 2) stage(2, 2, false);
+  // Q fragments of both query blocks -> AGPRs
+  {
+    uint32_t qw[2][8][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int qrow = min(qrow0 + 32 * b + ql, nq - 1);
+      const bf16 *qp = (qrow < nq0 ? q_a + (size_t)qrow * ldq : q_b + (size_t)(qrow - nq0) * ldq) + head * 128 + h * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const uint4 v = *(const uint4 *)(qp + ks * 16);
+        qw[b][ks][0] = v.x, qw[b][ks][1] = v.y, qw[b][ks][2] = v.z, qw[b][ks][3] = v.w;
+      }
+    }
+    CA_A4_WRITE_Q(qw);
+  }
+  CA_A4_ZERO_O();
+
   drain_and_barrier();
 
 #ifdef CA_A4_PLAIN   // bisecting aid: every tile the plain way (no pipelined stream), same prologue and epilogue

@@ -337,23 +337,35 @@ def gen_helpers():
                 L.append('  asm volatile("s_nop 7"); \\')
         L.append('  asm volatile("s_nop 15\\n\\ts_nop 7" : "+v"(S00), "+v"(S01), "+v"(S10), "+v"(S11)); } while (0)')
         L.append("")
-    # ---- plain O^T += V^T P^T of one tile: vbase = V slot byte offset (runtime)
+    # ---- plain O^T += V^T P^T of one tile: vbase = V slot byte offset (runtime).  The first 8 V fragments are read up
+    # front, fragment f + 7 into ring entry f - 1 behind the MFMAs of fragment f (one fragment = 2 MFMAs after the entry's
+    # last reader was issued); counted waits (the LDS returns data in order).
     # (its first statement takes every P fragment through an s_nop: hipcc pads no hazard INTO an asm statement, and a
     # pack -- VALU write -- right in front of the MFMA that reads it as B needs 2 wait states; without the operands
     # hipcc is free to sink the packs below a bare s_nop, and query block 0's first MFMA then read stale registers)
     allp = ", ".join(f'"+v"(P{kb}{qb}{sk})' for kb in range(2) for qb in range(2) for sk in range(2))
     L.append(f"#define CA_A4_PV_PLAIN(vbase) do {{ asm volatile(\"s_nop 7\" : {allp}); \\")
-    for f in range(16):
+    def v_read(f):
         kb, sk, db = f >> 3, (f >> 2) & 1, f & 3
         row = (32 * kb + 16 * sk) * 256
         ring = f & 7
         L.append(f'  asm volatile("ds_read_b64_tr_b16 {areg(AV + 4 * ring, 2)}, %0 offset:{row}" : : "v"(va0{db} + (vbase)) : "memory"); \\')
         L.append(f'  asm volatile("ds_read_b64_tr_b16 {areg(AV + 4 * ring + 2, 2)}, %0 offset:{row + 2048}" : : "v"(va1{db} + (vbase)) : "memory"); \\')
-        L.append('  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \\')
+    issued = []                       # fragments in issue order; a wait for fragment f allows 2 x (reads issued behind it)
+    for f in range(8):
+        v_read(f)
+        issued.append(f)
+    for f in range(16):
+        kb, sk, db = f >> 3, (f >> 2) & 1, f & 3
+        ring = f & 7
+        L.append(f'  asm volatile("s_waitcnt lgkmcnt({2 * (len(issued) - 1 - issued.index(f))})" ::: "memory"); \\')
         for qb in range(2):
             o = areg(AO + 16 * (qb * 4 + db), 16)
             L.append(f'  asm volatile("v_mfma_f32_32x32x16_bf16 {o}, {areg(AV + 4 * ring, 4)}, %0, {o}" : : "v"(P{kb}{qb}{sk})); \\')
-        L.append('  asm volatile("s_nop 3"); \\')
+        if 1 <= f <= 8:               # ring entry f - 1 is free: its readers were issued one fragment (2 MFMAs) ago
+            v_read(f + 7)
+            issued.append(f + 7)
+    L.append('  asm volatile("s_nop 3"); \\')
     L.append("  } while (0)")
     L.append("")
     return L
