@@ -694,18 +694,36 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
       const bf16 *nscale = (const bf16 *)(is_q ? P.norm_q : P.norm_k);
       float *part = (float *)smem;                // [2 halves][256 rows][4 column-waves]
       float x[8][2][8];
+      // RoPE values of this lane's 8 rows x 8 columns-in-head (the same for both heads of the tile) and the norm
+      // scales: every global load of this epilogue is issued here, before its first store, and waited for ONCE below.
+      // (Loaded next to their use, each load -- and, through hipcc's vmcnt(0) in front of every use, each fragment --
+      // waited for the acknowledgement of the previous fragment's stores: vmcnt retires in order and counts stores.
+      // Stamps of wave 0, per head of 8 fragments: 7500 -> 3700 cycles.)  Round 3: issued before the row sums are formed,
+      // so that their latency (4 000 cycles between issue and use on wave 0's stamps) runs beside that work.
+      // (the bias of both heads first: vmcnt retires in order, so the wait for a bias loaded behind the RoPE values
+      // would be a wait for all of them)
+      const int cih = wn * 32 + 8 * g;             // column inside the head
+      bf16x8 b8h[2] = {};
+      if (P.bias) {
+        b8h[0] = *(const bf16x8 *)((const bf16 *)P.bias + n0 + cih);
+        b8h[1] = *(const bf16x8 *)((const bf16 *)P.bias + n0 + 128 + cih);
+      }
+      const float qos = P.q_out_scale == 0.0f ? 1.0f : P.q_out_scale;
+      f32x4 rope0[8], rope1[8];
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1);
+        const float *rp = P.rope + (size_t)m * 128 + cih;  // [64 pairs][cos,sin]; pairs cih/2 .. cih/2+3
+        rope0[mi] = *(const f32x4 *)rp;
+        rope1[mi] = *(const f32x4 *)(rp + 4);
+      }
+      const bf16x8 s8 = *(const bf16x8 *)(nscale + cih);  // norm scales of this lane's 8 columns-in-head (both heads)
       __syncthreads();  // every wave has retired its own LDS-DMA (vmcnt 0 above): the LDS is reusable
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn) {
-        const int nb = n0 + hn * 128 + wn * 32 + 8 * g;
         float bias[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) bias[t] = 0.f;
-        if (P.bias) {
-          const bf16x8 b8 = *(const bf16x8 *)((const bf16 *)P.bias + nb);
-#pragma unroll
-          for (int t = 0; t < 8; ++t) bias[t] = (float)b8[t];
-        }
+        for (int t = 0; t < 8; ++t) bias[t] = P.bias ? (float)b8h[hn][t] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
           float sq = 0.f;
@@ -723,22 +741,6 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           if (g == 0) part[(hn * 256 + rl) * 4 + wn] = sq;
         }
       }
-      // RoPE values of this lane's 8 rows x 8 columns-in-head (the same for both heads of the tile) and the norm
-      // scales: every global load of this epilogue is issued here, before its first store, and waited for ONCE below.
-      // (Loaded next to their use, each load -- and, through hipcc's vmcnt(0) in front of every use, each fragment --
-      // waited for the acknowledgement of the previous fragment's stores: vmcnt retires in order and counts stores.
-      // Stamps of wave 0, per head of 8 fragments: 7500 -> 3700 cycles.)
-      const int cih = wn * 32 + 8 * g;             // column inside the head
-      const float qos = P.q_out_scale == 0.0f ? 1.0f : P.q_out_scale;
-      f32x4 rope0[8], rope1[8];
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-        const int m = min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1);
-        const float *rp = P.rope + (size_t)m * 128 + cih;  // [64 pairs][cos,sin]; pairs cih/2 .. cih/2+3
-        rope0[mi] = *(const f32x4 *)rp;
-        rope1[mi] = *(const f32x4 *)(rp + 4);
-      }
-      const bf16x8 s8 = *(const bf16x8 *)(nscale + cih);  // norm scales of this lane's 8 columns-in-head (both heads)
       CA_GSTAMP(4);
       __syncthreads();
       // every load of this epilogue has been issued: wait for them HERE, once, through the builtin.  Otherwise hipcc

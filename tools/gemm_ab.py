@@ -12,7 +12,7 @@ if not (len(sys.argv) == 2 and sys.argv[1].startswith("--run=")):
         out = f"/tmp/libca_gemm_ab_{i}.so"
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                                f"-I{src}", "-o", out] + flags.split() +
-                              [os.path.join(src, f) for f in ("ca_api.hip", "ca_gemm.hip", "ca_attn.hip", "ca_rowops.hip")])
+                              [os.path.join(src, f) for f in ("ca_api.hip", "ca_gemm.hip", "ca_attn.hip", "ca_attn4.hip", "ca_rowops.hip")])
         outs.append((flags, out))
     for rep in range(2):
         for flags, out in outs:

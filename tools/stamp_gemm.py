@@ -8,7 +8,7 @@ src = os.path.join(ROOT, "conceptattention_amd", "csrc")
 out = "/tmp/libca_gstamp.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                        "-DCA_GEMM_STAMP", "-o", out] +
-                      [os.path.join(src, f) for f in ("ca_api.hip", "ca_gemm.hip", "ca_attn.hip", "ca_rowops.hip")])
+                      [os.path.join(src, f) for f in ("ca_api.hip", "ca_gemm.hip", "ca_attn.hip", "ca_attn4.hip", "ca_rowops.hip")])
 from conceptattention_amd import _lib
 _lib.LIB_PATH = out
 import numpy as np

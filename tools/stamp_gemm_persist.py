@@ -8,8 +8,8 @@ sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "conceptattention_amd", "csrc")
 out = "/tmp/libca_gstamp2.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-DCA_GEMM_STAMP=2", "-o", out] + sys.argv[1:] +
-                      [os.path.join(src, f) for f in ("ca_api.hip", "ca_gemm.hip", "ca_attn.hip", "ca_rowops.hip")])
+                       "-DCA_GEMM_STAMP=2", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-o", out] + sys.argv[1:] +
+                      [os.path.join(src, f) for f in ("ca_api.hip", "ca_gemm.hip", "ca_attn.hip", "ca_attn4.hip", "ca_rowops.hip")])
 from conceptattention_amd import _lib
 _lib.LIB_PATH = out
 import numpy as np
