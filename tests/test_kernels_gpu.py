@@ -2,6 +2,7 @@
 same bf16-representable inputs.  Tolerances are stated per test: outputs are bf16 (8-bit mantissa,
 relative quantum 2^-8 = 3.9e-3), accumulation is fp32."""
 import math
+import os
 
 import pytest
 import torch
@@ -477,6 +478,19 @@ def test_attention_full_size(prescaled):
         q = q.float() / SL2
     ref = torch.cat([attn_ref(q[i:i + 1088], k, v, nh) for i in range(0, n, 1088)])
     close(out, ref, atol=5e-3)
+
+
+def test_attention_shape_fuzz():
+    """tools/fuzz_attn4.py: 80 random launches of the pre-scaled kernel (1-3 problems, 1-3 heads, query / key row counts
+    around the tile and workgroup boundaries, one or two key segments that are not adjacent in memory, one or two query
+    segments, padded row strides, fp32 output copies) against the fp32 reference, elementwise tolerance
+    6e-3 + 2^-7 |reference|."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_attn4.py"), "80", "3"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RESULT clean" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
 
 
 # ------------------------------------------------------------------------------------------ row kernels

@@ -13,11 +13,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "conceptattention_amd", "csrc")
 AB = os.path.join(ROOT, "tools", "ab_libs")
-VARIANTS = ["none", "nop4", "exp", "add", "exp,add", "cvt", "lds", "dma", "exp,add,cvt", "exp,add,cvt,lds,dma"]
+VARIANTS = ["none", "exp", "add", "exp,add", "cvt", "lds", "dma", "exp,add,cvt", "exp,add,cvt,lds,dma"]
+if os.environ.get("CA_A4_VARIANTS"):      # e.g. "none;order:valu_first;order:mem_first" (order:* = placement inside a gap)
+    VARIANTS = os.environ["CA_A4_VARIANTS"].split(";")
 
 
 def lib_of(v):
-    return os.path.join(AB, "ko_" + v.replace(",", "_"), "libca.so")
+    return os.path.join(AB, "ko_" + v.replace(",", "_").replace(":", "_"), "libca.so")
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
@@ -26,7 +28,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
         d = os.path.dirname(lib_of(v))
         os.makedirs(d, exist_ok=True)
         shutil.copy(os.path.join(SRC, "ca_attn4.hip"), d)
-        env = dict(os.environ, CA_A4_OUT=os.path.join(d, "ca_attn4_sched.inc"), CA_A4_KO="" if v == "none" else v)
+        env = dict(os.environ, CA_A4_OUT=os.path.join(d, "ca_attn4_sched.inc"))
+        env["CA_A4_ORDER" if v.startswith("order:") else "CA_A4_KO"] = "" if v == "none" else v.split(":")[-1]
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_attn4_schedule.py")], env=env,
                               stdout=subprocess.DEVNULL)
         obj = os.path.join(d, "ca_attn4.o")

@@ -30,6 +30,9 @@ OUT = os.environ.get("CA_A4_OUT") or os.path.join(ROOT, "conceptattention_amd", 
 # timing-only knock-outs (tools/attn4_knockouts.py; the results of such a build are wrong): a comma list of
 #   nop4 (s_nop 0 in place of the SGPR->VMEM s_nop 4), exp (v_mov for v_exp), add, cvt, lds (no LDS reads / waits), dma
 KO = set(filter(None, os.environ.get("CA_A4_KO", "").split(",")))
+# placement inside a gap (A/B aid): "split" = [MFMA, memory] | [VALU] as two statements (shipped), "valu_first" /
+# "mem_first" = one statement per slot
+ORDER = os.environ.get("CA_A4_ORDER", "split")
 
 AO, AQ, AK, AV = 0, 128, 192, 224
 TILE = 16384
@@ -214,26 +217,38 @@ def gen_iteration(r):
             o = areg(AO + 16 * (qb * 4 + db), 16)
             v = areg(AV + 4 * (f & 7), 4)
             st.ins(f"v_mfma_f32_32x32x16_bf16 {o}, {v}, {{0}}, {o}", (f"P{kb}{qb}{sk}", "r"))
-        if dma:
-            j, isv = dma
-            st.ins("buffer_load_dwordx4 {0}, {1}, {2} offen lds", (f"{'voff' if isv else 'koff'}{j}", "r"),
-                   ("DSV" if isv else "DSK", "rs"), ("SOV" if isv else "SOK", "rs"))
-        for rd in reads[s]:
-            if rd[0] == "k":
-                st.read_k(rd[1], rd[2], rd[3], rd[4])
-            else:
-                st.read_v(rd[1], rd[2], rd[3], rd[4], rd[5], rd[6])
-        st.flush()      # statement A: M0, wait, MFMA, DMA, LDS reads.  Statement B: the VALU fillers -- with a statement
-                        # between two MFMAs of one accumulation chain hipcc has no reason to pad an s_nop between them
-        seen = set()
-        for (kb, qb, sk, j) in cvt_of[s]:
-            assert (kb, qb, sk) not in seen        # one written element per vector variable and statement
-            seen.add((kb, qb, sk))
-            if "cvt" in KO:
-                continue
-            st.ins("v_cvt_pk_bf16_f32 {0}, {1}, {2}", (f"P{kb}{qb}{sk}[{j}]", "w"),
-                   (f"{S(kb, qb)}[{8 * sk + 2 * j}]", "r"), (f"{S(kb, qb)}[{8 * sk + 2 * j + 1}]", "r"))
-        exp_and_add(s)
+        def mem_ops():
+            if dma:
+                j, isv = dma
+                st.ins("buffer_load_dwordx4 {0}, {1}, {2} offen lds", (f"{'voff' if isv else 'koff'}{j}", "r"),
+                       ("DSV" if isv else "DSK", "rs"), ("SOV" if isv else "SOK", "rs"))
+            for rd in reads[s]:
+                if rd[0] == "k":
+                    st.read_k(rd[1], rd[2], rd[3], rd[4])
+                else:
+                    st.read_v(rd[1], rd[2], rd[3], rd[4], rd[5], rd[6])
+
+        def valu_ops():
+            seen = set()
+            for (kb, qb, sk, j) in cvt_of[s]:
+                assert (kb, qb, sk) not in seen        # one written element per vector variable and statement
+                seen.add((kb, qb, sk))
+                if "cvt" in KO:
+                    continue
+                st.ins("v_cvt_pk_bf16_f32 {0}, {1}, {2}", (f"P{kb}{qb}{sk}[{j}]", "w"),
+                       (f"{S(kb, qb)}[{8 * sk + 2 * j}]", "r"), (f"{S(kb, qb)}[{8 * sk + 2 * j + 1}]", "r"))
+            exp_and_add(s)
+
+        if ORDER == "split":
+            mem_ops()
+            st.flush()  # statement A: M0, wait, MFMA, DMA, LDS reads.  Statement B: the VALU fillers
+            valu_ops()
+        elif ORDER == "valu_first":     # one statement per slot: M0, wait, MFMA, the VALU fillers, then DMA / LDS reads
+            valu_ops()
+            mem_ops()
+        else:                           # "mem_first": one statement per slot, memory operations before the VALU fillers
+            mem_ops()
+            valu_ops()
         st.flush()
     check_schedule(exps_of, adds_of, cvt_of, reads, waits)
     return st.lines
