@@ -526,6 +526,21 @@ __global__ __launch_bounds__(256) void ca_axpy_kernel(bf16 *__restrict__ x, cons
   }
 }
 
+// the same with the state in fp32: x (fp32) += a * y (bf16)
+__global__ __launch_bounds__(256) void ca_axpy_f32_kernel(float *__restrict__ x, const bf16 *__restrict__ y, float a, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    const bf16x8 yv = *(const bf16x8 *)(y + i);
+    f32x4 x0 = *(const f32x4 *)(x + i), x1 = *(const f32x4 *)(x + i + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x0[j] = fmaf(a, (float)yv[j], x0[j]), x1[j] = fmaf(a, (float)yv[4 + j], x1[j]);
+    *(f32x4 *)(x + i) = x0;
+    *(f32x4 *)(x + i + 4) = x1;
+  } else {
+    for (long j = i; j < n; ++j) x[j] = fmaf(a, (float)y[j], x[j]);
+  }
+}
+
 // sinusoidal timestep embedding: out[v, 0:half] = cos(tf*t[v]*f_i), out[v, half:] = sin(...)
 __global__ __launch_bounds__(256) void ca_timestep_embedding_kernel(const float *__restrict__ t, int nt,
                                                                     float *__restrict__ out, int dim,
@@ -808,6 +823,7 @@ extern "C" int ca_heatmap_norm_accumulate(const float *logits, int32_t C, int32_
 }
 
 namespace {
+template <bool SILU>
 __global__ __launch_bounds__(256) void ca_silu_split_kernel(const float *__restrict__ x, int ldx, bf16 *__restrict__ hi,
                                                             bf16 *__restrict__ lo, int ldo, int rows, int K) {
   const int per_row = K >> 2;
@@ -817,7 +833,7 @@ __global__ __launch_bounds__(256) void ca_silu_split_kernel(const float *__restr
     bf16x4 h, l;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float s = ca_silu(v[j]);
+      const float s = SILU ? ca_silu(v[j]) : v[j];
       h[j] = (bf16)s;
       l[j] = (bf16)(s - (float)h[j]);
     }
@@ -836,9 +852,23 @@ extern "C" int ca_silu_split_bf16(const float *x, int32_t ldx, void *hi, void *l
   }
   const long n = (long)rows * (K / 4);
   const long blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
-  hipLaunchKernelGGL(ca_silu_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16 *)hi,
-                     (bf16 *)lo, ldo, rows, K);
+  hipLaunchKernelGGL(ca_silu_split_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (bf16 *)hi, (bf16 *)lo, ldo, rows, K);
   return check_launch("ca_silu_split_bf16");
+}
+
+extern "C" int ca_split_bf16(const float *x, int32_t ldx, void *hi, void *lo, int32_t ldo, int32_t rows, int32_t K,
+                             ca_stream_t stream) {
+  if (!x || !hi || !lo || rows < 1 || K < 4 || K % 4 || ldx < K || ldo < K || ldx % 4 || ldo % 4 ||
+      (((uintptr_t)x & 15) | (((uintptr_t)hi | (uintptr_t)lo) & 7))) {
+    ca_set_error("ca_split_bf16: bad arguments (rows=%d K=%d ldx=%d ldo=%d)", rows, K, ldx, ldo);
+    return CA_ERR_ARG;
+  }
+  const long n = (long)rows * (K / 4);
+  const long blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+  hipLaunchKernelGGL(ca_silu_split_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (bf16 *)hi, (bf16 *)lo, ldo, rows, K);
+  return check_launch("ca_split_bf16");
 }
 
 namespace {
@@ -886,6 +916,17 @@ extern "C" int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_strea
   hipLaunchKernelGGL(ca_axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16 *)x,
                      (const bf16 *)y, a, (long)n);
   return check_launch("ca_axpy_bf16");
+}
+
+extern "C" int ca_axpy_f32(float *x, const void *y, float a, int64_t n, ca_stream_t stream) {
+  if (!x || !y || n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) {
+    ca_set_error("ca_axpy_f32: bad arguments (n=%lld)", (long long)n);
+    return CA_ERR_ARG;
+  }
+  const long blocks = (n + 2047) / 2048;
+  hipLaunchKernelGGL(ca_axpy_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (const bf16 *)y, a,
+                     (long)n);
+  return check_launch("ca_axpy_f32");
 }
 
 extern "C" int ca_timestep_embedding_f32(const float *t, int32_t nt, float *out, int32_t dim, float time_factor,

@@ -208,6 +208,8 @@ class HipFluxDiT:
         # attention kernel's probability is a bare exp2 (include/conceptattn.h CA_ATTN_Q_PRESCALED); "0" = the kernel
         # multiplies every score instead (A/B aid)
         self.prescale_q = os.environ.get("CA_ATTN_PRESCALE", "1") != "0"
+        # sampling.denoise keeps the latent in fp32 between the Euler steps when the model says so (A/B: CA_FP32_LATENT=0)
+        self.fp32_latent = os.environ.get("CA_FP32_LATENT", "1") != "0"
         # The cross-attention-space vectors (post-QKNorm, pre-RoPE q) of the captured layers from the UNROUNDED
         # LayerNorm output: the bf16 rounding of that GEMM operand is ~90 % of the cross-space heat-map error
         # (tests/tools/error_budget.py: 3.3e-3 -> 3.5e-4 per map).  The LayerNorm writes a second bf16 plane with what
@@ -419,9 +421,22 @@ class HipFluxDiT:
         # ---- input embeddings: img_in, txt_in (text and concept tokens share txt_in, :105,120)
         self.TXT_IN[:g.oT].copy_(concepts.reshape(B * C, -1))
         self.TXT_IN[g.oT:].copy_(txt.reshape(B * T, -1))
-        img_in = img.reshape(B * Li, -1).to(bf).contiguous()
+        img_flat = img.reshape(B * Li, -1)
+        split_in = img.dtype == torch.float32 and self.residual_dtype == torch.float32
+        if split_in:
+            # an fp32 latent (sampling.denoise keeps the Euler state in fp32 on this path): img_in also sees what the
+            # bf16 rounding of its operand drops -- the same weights applied to the low plane, accumulated into the
+            # fp32 residual stream (K = 64: the second pass costs microseconds)
+            img_in = torch.empty(B * Li, img_flat.shape[1], device=img.device, dtype=bf)
+            img_lo = torch.empty_like(img_in)
+            ops.split_planes(img_flat.contiguous(), img_in, img_lo)
+        else:
+            img_in = img_flat.to(bf).contiguous()
         self._launch_gemm([ops.Gemm(img_in, W["img_in.weight"], W["img_in.bias"], X[g.oI:]),
                            ops.Gemm(self.TXT_IN, W["txt_in.weight"], W["txt_in.bias"], X[:g.oI])])
+        if split_in:
+            self._launch_gemm([ops.Gemm(img_lo, W["img_in.weight"], None, X[g.oI:], L.EPI_GATE_RESIDUAL,
+                                        resid=X[g.oI:], gate=self._ones_gate(W["img_in.weight"].shape[0]))])
 
         # ---- conditioning vectors: row 0 = vec (y), row 1 = concept_vec (modified_flux_dit.py:99-119)
         if cond_slot is not None:
@@ -547,6 +562,12 @@ class HipFluxDiT:
         mod2 = self.MOD.view(-1, self.weights.mod_rows)
         self._modulation_rows(self.VEC[:mod2.shape[0]], mod2)
         self._mod_cur = self.MOD
+
+    def _ones_gate(self, n: int) -> torch.Tensor:
+        g = getattr(self, "_ones_gate_vec", None)
+        if g is None or g.shape[0] != n:
+            g = self._ones_gate_vec = torch.ones(n, device=self.device, dtype=torch.float32)
+        return g
 
     def _q_out_scale(self) -> float:
         """What the qkv epilogue multiplies the rotated q by: softmax_scale * log2(e) (head_dim 128), or 0 (= 1)."""

@@ -414,6 +414,25 @@ def axpy(x, y, a: float) -> None:
     L.check(lib.ca_axpy_bf16(x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream()), "ca_axpy_bf16")
 
 
+def axpy_f32(x, y, a: float) -> None:
+    """x (fp32) += a*y (bf16): the Euler update with the latent kept in fp32 between the steps."""
+    lib = L.load()
+    _chk(x, torch.float32, "x"), _chk(y, torch.bfloat16, "y")
+    if not (x.is_contiguous() and y.is_contiguous()) or x.numel() != y.numel():
+        raise ValueError("axpy_f32: x,y must be contiguous with equal sizes")
+    L.check(lib.ca_axpy_f32(x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream()), "ca_axpy_f32")
+
+
+def split_planes(x, hi, lo) -> None:
+    """hi = bf16(x), lo = bf16(x - hi): x fp32 [rows,K] as two bf16 planes (~16 mantissa bits)."""
+    lib = L.load()
+    _chk(x, torch.float32, "x"), _chk(hi, torch.bfloat16, "hi"), _chk(lo, torch.bfloat16, "lo")
+    if x.dim() != 2 or hi.shape != x.shape or lo.shape != x.shape or hi.stride(0) != lo.stride(0):
+        raise ValueError("split_planes: x, hi, lo must be [rows,K] of one shape (hi / lo of one row stride)")
+    L.check(lib.ca_split_bf16(x.data_ptr(), x.stride(0), hi.data_ptr(), lo.data_ptr(), hi.stride(0), x.shape[0],
+                              x.shape[1], _stream()), "ca_split_bf16")
+
+
 def timestep_embedding(t, out, time_factor: float = 1000.0, max_period: float = 10000.0) -> None:
     """out[v,:] = [cos(tf*t[v]*f), sin(tf*t[v]*f)]; t fp32 [nt], out fp32 [nt, dim] contiguous."""
     lib = L.load()

@@ -128,6 +128,10 @@ def denoise_steps(model, img, img_ids, txt, txt_ids, vec, timesteps, guidance=4.
     enqueued (nothing is synchronised), so a caller can interleave several independent work items on
     different HIP streams; the generator's return value is denoise's (img, intermediates, dict)."""
     img = img.to(torch.bfloat16).contiguous().clone()
+    # HIP path: the Euler state is kept in fp32 between the steps (the reference re-rounds the running latent to bf16
+    # after every step, flux/sampling.py:141 on bf16 tensors: 2^-9 relative per step, accumulating; the fp32 oracle
+    # does not), and the model's img_in sees the fp32 value (HipFluxDiT: hi + lo planes).  Returned latents are bf16.
+    lat32 = img.float() if getattr(model, "fp32_latent", False) and getattr(model, "residual_dtype", None) == torch.float32 else None
     intermediates = [img.clone()] if return_intermediate_images else []
     out = {k: [] for k in DICT_KEYS} if return_vectors else {}
     guidance_vec = torch.full((img.shape[0],), guidance, device=img.device, dtype=torch.float32)
@@ -139,11 +143,16 @@ def denoise_steps(model, img, img_ids, txt, txt_ids, vec, timesteps, guidance=4.
     for it, (t_curr, t_prev) in enumerate(zip(timesteps[:-1], timesteps[1:])):
         t_vec = torch.full((img.shape[0],), t_curr, dtype=torch.float32, device=img.device)
         hm = heatmaps if (heatmaps is not None and (sel is None or it in sel)) else None
-        pred, d = model(img=img, img_ids=img_ids, txt=txt, txt_ids=txt_ids, concepts=concepts,
+        pred, d = model(img=img if lat32 is None else lat32, img_ids=img_ids, txt=txt, txt_ids=txt_ids, concepts=concepts,
                         concept_ids=concept_ids, concept_vec=concept_vec, y=vec, timesteps=t_vec,
                         guidance=guidance_vec, iteration=it, joint_attention_kwargs=joint_attention_kwargs,
                         return_vectors=return_vectors, heatmaps=hm, **({"cond_slot": it} if slots else {}))
-        ops.axpy(img, pred.contiguous(), t_prev - t_curr)  # img = img + (t_prev - t_curr) * pred  (:141)
+        if lat32 is None:
+            ops.axpy(img, pred.contiguous(), t_prev - t_curr)  # img = img + (t_prev - t_curr) * pred  (:141)
+        else:
+            ops.axpy_f32(lat32, pred.contiguous(), t_prev - t_curr)
+            if return_intermediate_images or it == len(timesteps) - 2:
+                img = lat32.to(torch.bfloat16)      # what the caller sees is bf16, as in the reference
         if return_intermediate_images:
             intermediates.append(img.clone())
         for k in out:

@@ -28,8 +28,8 @@
 extern "C" {
 #endif
 
-#define CA_VERSION 120 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
-                          CA_ATTN_Q_PRESCALED */
+#define CA_VERSION 121 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
+                          CA_ATTN_Q_PRESCALED; .1: ca_axpy_f32, ca_split_bf16 */
 
 #define CA_OK 0
 #define CA_ERR_ARG (-1)    /* bad shape / null pointer / misalignment */
@@ -272,6 +272,14 @@ int ca_timestep_embedding_f32(const float *t, int32_t nt, float *out, int32_t di
 
 /* Euler step of denoise(): x = x + a*y  (flux/sampling.py:141), bf16 in/out, fp32 math. */
 int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream);
+/* The same update with the latent kept in fp32 between the steps: x fp32 [n] += a * y (bf16 [n]).  The reference's
+ * loop (flux/sampling.py:141 on bf16 tensors) re-rounds the running latent after every step -- 2^-9 relative each
+ * time, accumulating; on this path the model's img_in then takes the fp32 value as two bf16 planes (ca_split_bf16). */
+int ca_axpy_f32(float *x, const void *y, float a, int64_t n, ca_stream_t stream);
+/* x fp32 [rows, K] (row stride ldx) -> hi = bf16(x), lo = bf16(x - hi) (row stride ldo), K % 4 == 0: the two planes of
+ * a GEMM operand that must not lose its low bits (ca_silu_split_bf16 without the silu): the latent into img_in
+ * (modified_flux_dit.py:98). */
+int ca_split_bf16(const float *x, int32_t ldx, void *hi, void *lo, int32_t ldo, int32_t rows, int32_t K, ca_stream_t stream);
 
 /* silu(x) of the conditioning vectors (Modulation: lin(silu(vec)), flux/modules/layers.py:113-126) split into two
  * bf16 planes, hi = bf16(s), lo = bf16(s - hi): hi + lo carries s to ~16 mantissa bits, so that the adaLN modulation

@@ -36,12 +36,12 @@ REPORT = {}
 # q vectors come from the unrounded LayerNorm output (HipFluxDiT.split_q_capture); at steps >= 1 of a generation the
 # latent itself has moved (pred: 0.24-0.37 % rms off the fp32 trajectory after 57 bf16 blocks per step) and the
 # cross-space logits amplify that: 2-4e-3 per map, 1.07e-3 for the 16-map mean.
-FINAL_OUT_BOUND = 9e-4            # schnell 4 steps: 5.9e-4; dev 2 steps: 2.8e-4
-FINAL_CROSS_BOUND = 1.6e-3        # schnell 4 steps: 1.07e-3; dev 2 steps: 3.9e-4; encode: 1.6e-4
-SINGLE_OUT_BOUND = 4.0e-3         # any (step, layer): <= 2.72e-3 (step 3); step 0: <= 1.48e-3
+FINAL_OUT_BOUND = 5.1e-4          # schnell 4 steps: 3.4e-4; dev 2 steps: 2.4e-4   (fp32 Euler state + hi/lo img_in, round 3)
+FINAL_CROSS_BOUND = 3.6e-4        # schnell 4 steps: 2.4e-4 (bf16 Euler state: 1.05e-3); dev 2 steps: 1.0e-4; encode: 1.6e-4
+SINGLE_OUT_BOUND = 3.4e-3         # any (step, layer): <= 2.23e-3 (step 3); step 0: <= 1.63e-3
 SINGLE_OUT_STEP0_BOUND = 2.2e-3
-SINGLE_CROSS_BOUND = 6.5e-3       # any (step, layer): <= 4.34e-3 (step 3)
-SINGLE_CROSS_SAME_INPUT_BOUND = 7.5e-4   # step 0 / encode path (the oracle's own input): <= 4.8e-4
+SINGLE_CROSS_BOUND = 1.55e-3      # any (step, layer): <= 1.02e-3 (bf16 Euler state: 4.3e-3)
+SINGLE_CROSS_SAME_INPUT_BOUND = 6.3e-4   # step 0 / encode path (the oracle's own input): <= 4.2e-4
 ENCODE_FINAL_OUT_BOUND = 1.5e-3   # one forward, mean of 4 layers: 9.6e-4
 ENCODE_FINAL_CROSS_BOUND = 2.5e-4 # 1.6e-4
 
@@ -76,16 +76,21 @@ def run_steps(pl, inp, steps, per_layer=True, ts=None, guidance=0.0):
     out = torch.zeros(steps, p.depth, C, L_, device=DEV)
     cross = torch.zeros(steps, p.depth, C, L_, device=DEV)
     preds = []
+    lat32 = img.float() if getattr(m, "fp32_latent", False) else None    # the Euler state as sampling.denoise_steps keeps it
     m.precompute_conditioning(ts[:-1], prep["vec"], con_vec, guidance)
     for s, (tc, tp) in enumerate(zip(ts[:-1], ts[1:])):
         req = HeatmapRequest(tuple(range(p.depth)), 0.0, torch.zeros(C, L_, device=DEV), torch.zeros(C, L_, device=DEV),
                              per_layer_out=out[s], per_layer_cross=cross[s], per_layer_weight=1.0)
-        pred, _ = m(img=img, img_ids=prep["img_ids"], txt=prep["txt"], txt_ids=prep["txt_ids"], concepts=con,
+        pred, _ = m(img=img if lat32 is None else lat32, img_ids=prep["img_ids"], txt=prep["txt"], txt_ids=prep["txt_ids"], concepts=con,
                     concept_ids=con_ids, concept_vec=con_vec, y=prep["vec"],
                     timesteps=torch.full((1,), tc, device=DEV), guidance=torch.full((1,), guidance, device=DEV),
                     return_vectors=False, heatmaps=req, cond_slot=s)
         preds.append(pred.float().cpu())
-        ops.axpy(img, pred.contiguous(), tp - tc)
+        if lat32 is None:
+            ops.axpy(img, pred.contiguous(), tp - tc)
+        else:
+            ops.axpy_f32(lat32, pred.contiguous(), tp - tc)
+            img = lat32.to(torch.bfloat16)
     torch.cuda.synchronize()
     return out.cpu().numpy(), cross.cpu().numpy(), preds, img.float().cpu()
 

@@ -602,3 +602,33 @@ def test_axpy():
     ref2 = x2.float() + 2 * y2[:1000].float()
     ops.axpy(x2, y2[:1000].clone(), 2.0)
     close(x2, ref2, atol=1e-3)
+
+
+def test_axpy_f32_and_split_planes():
+    """The fp32 Euler state: x += a y in fp32 (exactly one fma per element), and the two bf16 planes of an fp32 operand
+    (hi = bf16(x), lo = bf16(x - hi), together ~16 mantissa bits) with which img_in sees it (two GEMM passes)."""
+    x = torch.randn(4096 * 64 + 5, device=DEV)[:4096 * 64].clone()
+    y = rnd(4096, 64, seed=9)
+    ref = torch.addcmul(x.double(), y.double().flatten(), torch.tensor(-0.25, dtype=torch.float64, device=DEV))
+    ops.axpy_f32(x, y, -0.25)
+    assert (x.double() - ref).abs().max() <= 2.0 ** -23 * ref.abs().max()
+    x3 = torch.randn(1003, device=DEV)
+    y3 = rnd(1003, seed=2)
+    r3 = x3 + 2.0 * y3.float()
+    ops.axpy_f32(x3, y3, 2.0)
+    assert (x3 - r3).abs().max() <= 1e-6
+    v = torch.randn(300, 64, device=DEV) * 3
+    hi, lo = torch.empty(300, 64, device=DEV, dtype=torch.bfloat16), torch.empty(300, 64, device=DEV, dtype=torch.bfloat16)
+    ops.split_planes(v, hi, lo)
+    assert torch.equal(hi, v.bfloat16()) and torch.equal(lo, (v - v.bfloat16().float()).bfloat16())
+    assert (hi.float() + lo.float() - v).abs().max() <= 2.0 ** -16 * v.abs().max()
+    # the two planes through the GEMM: W (hi + lo) to fp32 accuracy of the operand
+    w, b = rnd(256, 64, scale=0.3), rnd(256)
+    out = torch.zeros(300, 256, device=DEV)
+    ops.gemm([ops.Gemm(hi, w, b, out)])
+    ops.gemm([ops.Gemm(lo, w, None, out, L.EPI_GATE_RESIDUAL, resid=out, gate=torch.ones(256, device=DEV))])
+    ref_g = v.double() @ w.double().t() + b.double()
+    one_plane = hi.double() @ w.double().t() + b.double()
+    assert (out.double() - ref_g).abs().max() < 0.02 * (one_plane - ref_g).abs().max() + 1e-5
+    with pytest.raises(ValueError):
+        ops.split_planes(v, hi, lo[:, :32])
