@@ -526,14 +526,24 @@ __global__ __launch_bounds__(256) void ca_axpy_kernel(bf16 *__restrict__ x, cons
   }
 }
 
-// the same with the state in fp32: x (fp32) += a * y (bf16)
-__global__ __launch_bounds__(256) void ca_axpy_f32_kernel(float *__restrict__ x, const bf16 *__restrict__ y, float a, long n) {
+// the same with the state in fp32: x (fp32) += a * y (bf16 or fp32)
+template <typename TY>
+__global__ __launch_bounds__(256) void ca_axpy_f32_kernel(float *__restrict__ x, const TY *__restrict__ y, float a, long n) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i + 8 <= n) {
-    const bf16x8 yv = *(const bf16x8 *)(y + i);
+    float yv[8];
+    if constexpr (sizeof(TY) == 2) {
+      const bf16x8 y8 = *(const bf16x8 *)(y + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yv[j] = (float)y8[j];
+    } else {
+      const f32x4 y0 = *(const f32x4 *)(y + i), y1 = *(const f32x4 *)(y + i + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) yv[j] = y0[j], yv[4 + j] = y1[j];
+    }
     f32x4 x0 = *(const f32x4 *)(x + i), x1 = *(const f32x4 *)(x + i + 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x0[j] = fmaf(a, (float)yv[j], x0[j]), x1[j] = fmaf(a, (float)yv[4 + j], x1[j]);
+    for (int j = 0; j < 4; ++j) x0[j] = fmaf(a, yv[j], x0[j]), x1[j] = fmaf(a, yv[4 + j], x1[j]);
     *(f32x4 *)(x + i) = x0;
     *(f32x4 *)(x + i + 4) = x1;
   } else {
@@ -918,14 +928,18 @@ extern "C" int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_strea
   return check_launch("ca_axpy_bf16");
 }
 
-extern "C" int ca_axpy_f32(float *x, const void *y, float a, int64_t n, ca_stream_t stream) {
+extern "C" int ca_axpy_f32(float *x, const void *y, int32_t y_is_f32, float a, int64_t n, ca_stream_t stream) {
   if (!x || !y || n < 1 || (((uintptr_t)x | (uintptr_t)y) & 15)) {
     ca_set_error("ca_axpy_f32: bad arguments (n=%lld)", (long long)n);
     return CA_ERR_ARG;
   }
   const long blocks = (n + 2047) / 2048;
-  hipLaunchKernelGGL(ca_axpy_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (const bf16 *)y, a,
-                     (long)n);
+  if (y_is_f32)
+    hipLaunchKernelGGL(ca_axpy_f32_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                       (const float *)y, a, (long)n);
+  else
+    hipLaunchKernelGGL(ca_axpy_f32_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                       (const bf16 *)y, a, (long)n);
   return check_launch("ca_axpy_f32");
 }
 

@@ -323,6 +323,7 @@ class HipFluxDiT:
             ATT32=torch.zeros(max(B * C, 1), H, **f32),  # fp32 copy of the concept attention rows
             TXT_IN=torch.zeros(B * (C + T), p.context_in_dim, **bf),
             PRED=torch.zeros(B * L_img, p.in_channels, **bf),
+            PRED32=torch.zeros(B * L_img, p.in_channels, **f32),
             ROPE=torch.zeros(n, 64, 2, **f32),
             TEMB=torch.zeros(2 * B, 256, **f32),      # rows 2j / 2j+1: item j's vec / concept_vec chain
             TVAL=torch.zeros(2 * B, **f32),
@@ -461,8 +462,10 @@ class HipFluxDiT:
         fm = "final_layer.adaLN_modulation.1"
         ops.ln_modulate(X[g.oI:], XM[g.oI:], [((j + 1) * Li, self._mod(fm, 0, 0, j), self._mod(fm, 0, 1, j))
                                               for j in range(B)])
-        self._launch_gemm([ops.Gemm(XM[g.oI:], W["final_layer.linear.weight"], W["final_layer.linear.bias"], self.PRED)])
-        return self.PRED.view(B, Li, -1).clone(), out
+        # the prediction has the latent's type: an fp32 latent (sampling.denoise on this path) gets it unrounded
+        pred = self.PRED32 if split_in else self.PRED
+        self._launch_gemm([ops.Gemm(XM[g.oI:], W["final_layer.linear.weight"], W["final_layer.linear.bias"], pred)])
+        return pred.view(B, Li, -1).clone(), out
 
     def _vec_chain(self, tv, yin, gv, hv, vecs):
         """vec = time_in(t) (+ guidance_in(g)) + vector_in(y) for every row of tv / yin (MLPEmbedders,

@@ -415,12 +415,16 @@ def axpy(x, y, a: float) -> None:
 
 
 def axpy_f32(x, y, a: float) -> None:
-    """x (fp32) += a*y (bf16): the Euler update with the latent kept in fp32 between the steps."""
+    """x (fp32) += a*y (bf16 or fp32): the Euler update with the latent kept in fp32 between the steps."""
     lib = L.load()
-    _chk(x, torch.float32, "x"), _chk(y, torch.bfloat16, "y")
+    _chk(x, torch.float32, "x")
+    if y.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("axpy_f32: y must be bf16 or fp32")
+    _chk(y, y.dtype, "y")
     if not (x.is_contiguous() and y.is_contiguous()) or x.numel() != y.numel():
         raise ValueError("axpy_f32: x,y must be contiguous with equal sizes")
-    L.check(lib.ca_axpy_f32(x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream()), "ca_axpy_f32")
+    L.check(lib.ca_axpy_f32(x.data_ptr(), y.data_ptr(), int(y.dtype == torch.float32), float(a), x.numel(), _stream()),
+            "ca_axpy_f32")
 
 
 def split_planes(x, hi, lo) -> None:

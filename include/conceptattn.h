@@ -272,10 +272,11 @@ int ca_timestep_embedding_f32(const float *t, int32_t nt, float *out, int32_t di
 
 /* Euler step of denoise(): x = x + a*y  (flux/sampling.py:141), bf16 in/out, fp32 math. */
 int ca_axpy_bf16(void *x, const void *y, float a, int64_t n, ca_stream_t stream);
-/* The same update with the latent kept in fp32 between the steps: x fp32 [n] += a * y (bf16 [n]).  The reference's
- * loop (flux/sampling.py:141 on bf16 tensors) re-rounds the running latent after every step -- 2^-9 relative each
- * time, accumulating; on this path the model's img_in then takes the fp32 value as two bf16 planes (ca_split_bf16). */
-int ca_axpy_f32(float *x, const void *y, float a, int64_t n, ca_stream_t stream);
+/* The same update with the latent kept in fp32 between the steps: x fp32 [n] += a * y (y bf16 [n], or fp32 [n] if
+ * y_is_f32: the model's prediction unrounded).  The reference's loop (flux/sampling.py:141 on bf16 tensors) re-rounds
+ * the running latent after every step -- 2^-9 relative each time, accumulating; on this path the model's img_in then
+ * takes the fp32 value as two bf16 planes (ca_split_bf16). */
+int ca_axpy_f32(float *x, const void *y, int32_t y_is_f32, float a, int64_t n, ca_stream_t stream);
 /* x fp32 [rows, K] (row stride ldx) -> hi = bf16(x), lo = bf16(x - hi) (row stride ldo), K % 4 == 0: the two planes of
  * a GEMM operand that must not lose its low bits (ca_silu_split_bf16 without the silu): the latent into img_in
  * (modified_flux_dit.py:98). */

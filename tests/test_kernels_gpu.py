@@ -617,6 +617,10 @@ def test_axpy_f32_and_split_planes():
     r3 = x3 + 2.0 * y3.float()
     ops.axpy_f32(x3, y3, 2.0)
     assert (x3 - r3).abs().max() <= 1e-6
+    x4, y4 = torch.randn(70001, device=DEV), torch.randn(70001, device=DEV)       # fp32 y: the unrounded prediction
+    r4 = torch.addcmul(x4.double(), y4.double(), torch.tensor(0.125, dtype=torch.float64, device=DEV))
+    ops.axpy_f32(x4, y4, 0.125)
+    assert (x4.double() - r4).abs().max() <= 2.0 ** -23 * r4.abs().max()
     v = torch.randn(300, 64, device=DEV) * 3
     hi, lo = torch.empty(300, 64, device=DEV, dtype=torch.bfloat16), torch.empty(300, 64, device=DEV, dtype=torch.bfloat16)
     ops.split_planes(v, hi, lo)

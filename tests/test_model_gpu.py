@@ -47,6 +47,18 @@ def run_hip(p, sd, inp, t, guidance=None, **kw):
                 guidance=None if guidance is None else torch.tensor([guidance], device=DEV), **kw)
 
 
+def test_prediction_follows_the_latent_dtype():
+    """bf16 latent in -> bf16 prediction out (the reference's call); fp32 latent in -> img_in over its hi + lo planes and
+    an fp32 prediction.  For a bf16-representable latent the low plane is zero, so the two calls agree bit for bit
+    after the one rounding."""
+    p, sd, inp = tiny_case(False)
+    lat = inp["latent"].bfloat16()
+    _, (pred_b, _) = run_hip(p, sd, dict(inp, latent=lat), 0.75, 3.5)
+    _, (pred_f, _) = run_hip(p, sd, dict(inp, latent=lat.float()), 0.75, 3.5)
+    assert pred_b.dtype == torch.bfloat16 and pred_f.dtype == torch.float32
+    assert torch.equal(pred_f.bfloat16(), pred_b)
+
+
 @pytest.mark.parametrize("guidance_embed", [False, True])
 def test_tiny_model_matches_oracle(guidance_embed):
     p, sd, inp = tiny_case(guidance_embed)
@@ -55,7 +67,9 @@ def test_tiny_model_matches_oracle(guidance_embed):
                                 inp["concepts"], inp["concept_ids"], inp["concept_vec"], torch.tensor([t]),
                                 inp["vec"], torch.tensor([g]))
     _, (pred, d) = run_hip(p, sd, inp, t, g)
-    assert pred.shape == pred_o.shape and pred.dtype == torch.bfloat16
+    # the prediction has the latent's type: fp32 in (the fp32 Euler state of sampling.denoise: hi + lo planes into
+    # img_in, unrounded prediction out), bf16 in -> bf16 out (the reference's call)
+    assert pred.shape == pred_o.shape and pred.dtype == torch.float32
     for k in DICT_KEYS:
         assert tuple(d[k].shape) == tuple(d_o[k].shape), k
         scale = d_o[k].abs().max().item()
