@@ -398,8 +398,8 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
       ca_set_error("ca_attn_fwd_bf16[%d]: null pointer or empty shape (nq=%d n0=%d n1=%d)", i, p.nq, p.n0, p.n1);
       return CA_ERR_ARG;
     }
-    if (p.nq0 < 0 || p.nq0 > p.nq || (p.nq0 > 0 && p.nq0 < p.nq && (!p.q1 || !p.out1 || p.out_f32))) {
-      ca_set_error("ca_attn_fwd_bf16[%d]: two query segments need 0 < nq0 < nq, q1 and out1 (and no out_f32)", i);
+    if (p.nq0 < 0 || p.nq0 > p.nq || (p.nq0 > 0 && p.nq0 < p.nq && (!p.q1 || !p.out1))) {
+      ca_set_error("ca_attn_fwd_bf16[%d]: two query segments need 0 < nq0 < nq, q1 and out1", i);
       return CA_ERR_ARG;
     }
     if (p.ldq % 8 || p.ldo % 8 || p.ldkv % 8 || p.ldq < num_heads * 128 || p.ldo < num_heads * 128 ||

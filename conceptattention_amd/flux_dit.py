@@ -210,6 +210,7 @@ class HipFluxDiT:
         self.prescale_q = os.environ.get("CA_ATTN_PRESCALE", "1") != "0"
         # sampling.denoise keeps the latent in fp32 between the Euler steps when the model says so (A/B: CA_FP32_LATENT=0)
         self.fp32_latent = os.environ.get("CA_FP32_LATENT", "1") != "0"
+        self.f32_image_vectors = os.environ.get("CA_F32_IMAGE_VECTORS", "1") != "0"
         # The cross-attention-space vectors (post-QKNorm, pre-RoPE q) of the captured layers from the UNROUNDED
         # LayerNorm output: the bf16 rounding of that GEMM operand is ~90 % of the cross-space heat-map error
         # (tests/tools/error_budget.py: 3.3e-3 -> 3.5e-4 per map).  The LayerNorm writes a second bf16 plane with what
@@ -321,6 +322,10 @@ class HipFluxDiT:
             XML=torch.zeros(n, H, **bf),    # low plane of XM (captured layers): bf16(y - float(bf16(y)))
             QD=torch.zeros(n, H, **f32),    # its q projection: the correction ops.qpre_finish adds before the norm
             ATT32=torch.zeros(max(B * C, 1), H, **f32),  # fp32 copy of the concept attention rows
+            # ... and of each item's [text | image] attention rows in the layers whose maps are requested: the output-space
+            # logits are dot products over 3072 dims of two attention outputs, and the bf16 rounding of the image side
+            # was the largest remaining error of a single output-space map (the text rows ride along unused)
+            ATTI32=torch.zeros(B, T + L_img, H, **f32),
             TXT_IN=torch.zeros(B * (C + T), p.context_in_dim, **bf),
             PRED=torch.zeros(B * L_img, p.in_channels, **bf),
             PRED32=torch.zeros(B * L_img, p.in_channels, **f32),
@@ -566,6 +571,11 @@ class HipFluxDiT:
         self._modulation_rows(self.VEC[:mod2.shape[0]], mod2)
         self._mod_cur = self.MOD
 
+    def _f32_image_vectors(self, capture: bool, heatmaps) -> bool:
+        """The attention kernel writes an fp32 copy of the [text | image] output rows in captured layers when the maps
+        are reduced on the device (fused heat-map path); A/B: CA_F32_IMAGE_VECTORS=0."""
+        return bool(capture and heatmaps is not None and self.f32_image_vectors and self.precision != "fp8")
+
     def _ones_gate(self, n: int) -> torch.Tensor:
         g = getattr(self, "_ones_gate_vec", None)
         if g is None or g.shape[0] != n:
@@ -652,7 +662,8 @@ class HipFluxDiT:
             self.ATT32[:oT].copy_(vs[:oT])
         for j in range(B):
             tj, ij = slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)
-            probs.append(ops.Attn(qs[tj], ATT[tj], ks[tj], vs[tj], ks[ij], vs[ij], q1=qs[ij], out1=ATT[ij]))
+            probs.append(ops.Attn(qs[tj], ATT[tj], ks[tj], vs[tj], ks[ij], vs[ij], q1=qs[ij], out1=ATT[ij],
+                                  out_f32=self.ATTI32[j] if self._f32_image_vectors(capture, heatmaps) else None))
         ops.attention(probs, NH, q_prescaled=self.prescale_q)
         if capture:
             self._capture(out, i, g, NH, return_vectors, heatmaps)
@@ -737,7 +748,8 @@ class HipFluxDiT:
             # is the dominant heat-map error otherwise -- DESIGN.md "tolerance")
             li = hm.layer_indices.index(layer)
             cj, ij = slice(j * C, (j + 1) * C), slice(oI + j * Li, oI + (j + 1) * Li)
-            for img_vec, con_vec, acc, table in ((ATT[ij], self.ATT32[cj], hm.out_space, hm.per_layer_out),
+            img_out = self.ATTI32[j, g.T:] if self._f32_image_vectors(True, heatmaps) else ATT[ij]
+            for img_vec, con_vec, acc, table in ((img_out, self.ATT32[cj], hm.out_space, hm.per_layer_out),
                                                  (QPRE[ij], QPRE[cj], hm.cross_space, hm.per_layer_cross)):
                 ops.heatmap_logits(img_vec, con_vec, self.LOGITS[:C])
                 ops.heatmap_softmax_accumulate(self.LOGITS[:C], acc, hm.weight, hm.norm)

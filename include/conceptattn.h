@@ -150,8 +150,10 @@ typedef struct {
   void *out;     /* bf16, row stride ldo */
   const void *k0, *v0; /* segment 0: n0 rows, row stride ldkv */
   const void *k1, *v1; /* segment 1: n1 rows, row stride ldkv */
-  float *out_f32; /* optional fp32 copy of the output rows (row stride ldo32), or NULL: used for the
-                     C concept rows so the heat-map products do not see their bf16 rounding */
+  float *out_f32; /* optional fp32 copy of the output rows [nq, heads*128] (row stride ldo32; indexed by the
+                     problem's row number, also with two query segments), or NULL: used for the C concept rows and,
+                     in the layers whose maps are requested, for the image rows, so that the heat-map products
+                     (concept_attention_pipeline.py:57-62) see neither side's bf16 rounding */
   const void *q1; /* second query segment (rows nq0..nq-1), row stride ldq; or NULL */
   void *out1;     /* its output rows, row stride ldo */
   int32_t nq, n0, n1;
