@@ -49,6 +49,12 @@ __device__ __forceinline__ uint2 ca_pack_fp8x8(const float *y) {
 // LO (bf16 output only): a second plane out_lo = bf16(y - float(bf16(y))), the part of the modulated row its bf16
 // rounding drops; out + out_lo carries ~16 mantissa bits (the q projection of the layers whose cross-attention-space
 // vectors are captured is corrected with a product of this plane).
+// y = (1 + scale) * ((v - mean) * rstd) + shift, with its one fused multiply-add spelled out (both LayerNorm kernels
+// must round alike: a 5-item forward and a single-item one may run different ones)
+__device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float scale1, float shift) {
+  return __builtin_fmaf(scale1, (v - mean) * rstd, shift);
+}
+
 template <bool FP8, typename XT = bf16, bool LO = false>
 __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const XT *__restrict__ x, int ldx,
                                                              void *__restrict__ out_, int ldo, int M, int H,
@@ -115,8 +121,8 @@ __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const XT *__restric
       float y[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        y[j] = (1.f + sc0[j]) * ((v[c][j] - mean) * rstd) + sh0[j];
-        y[4 + j] = (1.f + sc1[j]) * ((v[c][4 + j] - mean) * rstd) + sh1[j];
+        y[j] = ln_apply(v[c][j], mean, rstd, 1.f + sc0[j], sh0[j]);
+        y[4 + j] = ln_apply(v[c][4 + j], mean, rstd, 1.f + sc1[j], sh1[j]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -161,6 +167,91 @@ __global__ __launch_bounds__(256) void ca_ln_modulate_kernel(const XT *__restric
         *(uint2 *)(orow + k) = ca_pack_fp8x8(y);
       }
     }
+  }
+}
+
+// The same LayerNorm + modulation for the model's own shape (fp32 residual stream in, bf16 out, H = NCH x 512), with a
+// wave walking ROWS_PER_WAVE consecutive rows: the shift / scale vectors of the rows' segment (24 KB per row at
+// H = 3072, twice the row itself) stay in registers across the rows instead of being pulled through L2 for every
+// row.  Per row the arithmetic is ca_ln_modulate_kernel's,
+// operation for operation (same summation order, same fused multiply-adds): the two kernels agree bit for bit.
+constexpr int LN_ROWS_PER_WAVE = 8;
+template <int NCH, bool LO>
+__global__ __launch_bounds__(256, 2) void ca_ln_modulate_rows_kernel(const float *__restrict__ x, int ldx,
+                                                                  bf16 *__restrict__ out, int ldo, int M, float eps,
+                                                                  const LnArgs A, bf16 *__restrict__ out_lo, int ldlo) {
+  constexpr int H = NCH * 512;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int row0 = wave * LN_ROWS_PER_WAVE;
+  if (row0 >= M) return;
+  const int nrows = min(LN_ROWS_PER_WAVE, M - row0);
+  float sc1[NCH][8], sh[NCH][8];   // 1 + scale, shift of the current segment
+  int cur_seg = -1;
+  float v[1][NCH][8];
+  auto load_row = [&](int buf, int row) {
+    const float *xr = x + (size_t)row * ldx + lane * 8;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const f32x4 t0 = *(const f32x4 *)(xr + c * 512), t1 = *(const f32x4 *)(xr + c * 512 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[buf][c][j] = t0[j], v[buf][c][4 + j] = t1[j];
+    }
+  };
+  auto do_row = [&](int buf, int row) {
+    int si = 0;
+#pragma unroll
+    for (int s = 0; s < CA_MAX_SEGMENTS - 1; ++s)
+      if (s + 1 < A.n_segs && row >= A.seg[s].row_end) si = s + 1;
+    if (si != cur_seg) {   // (wave-uniform; once per wave except where its rows cross a segment boundary)
+      cur_seg = si;
+      const float *scale = A.seg[si].scale + lane * 8, *shift = A.seg[si].shift + lane * 8;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const f32x4 a0 = *(const f32x4 *)(scale + c * 512), a1 = *(const f32x4 *)(scale + c * 512 + 4);
+        const f32x4 b0 = *(const f32x4 *)(shift + c * 512), b1 = *(const f32x4 *)(shift + c * 512 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sc1[c][j] = 1.f + a0[j], sc1[c][4 + j] = 1.f + a1[j];
+          sh[c][j] = b0[j], sh[c][4 + j] = b1[j];
+        }
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[buf][c][j];
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[buf][c][j] - mean;
+        sq += d * d;
+      }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = ln_apply(v[buf][c][j], mean, rstd, sc1[c][j], sh[c][j]);
+      const int k = c * 512 + lane * 8;
+      *(uint4 *)(out + (size_t)row * ldo + k) =
+          make_uint4(ca_pack2(y[0], y[1]), ca_pack2(y[2], y[3]), ca_pack2(y[4], y[5]), ca_pack2(y[6], y[7]));
+      if constexpr (LO) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = y[j] - (float)(bf16)y[j];
+        *(uint4 *)(out_lo + (size_t)row * ldlo + k) =
+            make_uint4(ca_pack2(r[0], r[1]), ca_pack2(r[2], r[3]), ca_pack2(r[4], r[5]), ca_pack2(r[6], r[7]));
+      }
+    }
+  };
+  for (int i = 0; i < nrows; ++i) {   // (two waves per SIMD; requesting the next row ahead of the reduction -- a second row
+    load_row(0, row0 + i);            // buffer, 254 registers -- measured no faster: 82.7 us either way, 4.85 TB/s)
+    do_row(0, row0 + i);
   }
 }
 
@@ -610,6 +701,18 @@ int ln_modulate_impl(const char *FN, const void *x, int32_t ldx, void *out, int3
   }
   const dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
+  static const bool rows_kernel = !(getenv("CA_LN_ROWS") && atoi(getenv("CA_LN_ROWS")) == 0);
+  if (rows_kernel && x_f32 && !fp8 && H == 3072) {   // the model's shape: a wave walks 8 rows (vectors kept in registers)
+    const int waves = (M + LN_ROWS_PER_WAVE - 1) / LN_ROWS_PER_WAVE;
+    const dim3 g2((waves + 3) / 4);
+    if (out_lo)
+      hipLaunchKernelGGL((ca_ln_modulate_rows_kernel<6, true>), g2, block, 0, st, (const float *)x, ldx, (bf16 *)out, ldo,
+                         M, eps, A, (bf16 *)out_lo, ldlo);
+    else
+      hipLaunchKernelGGL((ca_ln_modulate_rows_kernel<6, false>), g2, block, 0, st, (const float *)x, ldx, (bf16 *)out, ldo,
+                         M, eps, A, (bf16 *)nullptr, 0);
+    return check_launch(FN);
+  }
   if (out_lo)
     hipLaunchKernelGGL((ca_ln_modulate_kernel<false, float, true>), grid, block, 0, st, (const float *)x, ldx, out, ldo,
                        M, H, eps, (float *)nullptr, A, (bf16 *)out_lo, ldlo);
