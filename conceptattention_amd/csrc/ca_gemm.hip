@@ -710,14 +710,18 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
       }
       const float qos = P.q_out_scale == 0.0f ? 1.0f : P.q_out_scale;
       f32x4 rope0[8], rope1[8];
+      bf16x8 s8;                                   // norm scales of this lane's 8 columns-in-head (both heads)
+      auto load_rope = [&]() {
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-        const int m = min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1);
-        const float *rp = P.rope + (size_t)m * 128 + cih;  // [64 pairs][cos,sin]; pairs cih/2 .. cih/2+3
-        rope0[mi] = *(const f32x4 *)rp;
-        rope1[mi] = *(const f32x4 *)(rp + 4);
-      }
-      const bf16x8 s8 = *(const bf16x8 *)(nscale + cih);  // norm scales of this lane's 8 columns-in-head (both heads)
+        for (int mi = 0; mi < 8; ++mi) {
+          const int m = min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1);
+          const float *rp = P.rope + (size_t)m * 128 + cih;  // [64 pairs][cos,sin]; pairs cih/2 .. cih/2+3
+          rope0[mi] = *(const f32x4 *)rp;
+          rope1[mi] = *(const f32x4 *)(rp + 4);
+        }
+        s8 = *(const bf16x8 *)(nscale + cih);
+      };
+      if constexpr (!FP8) load_rope();   // (the fp8 instantiation has no registers for it here: behind the row sums)
       __syncthreads();  // every wave has retired its own LDS-DMA (vmcnt 0 above): the LDS is reusable
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn) {
@@ -741,6 +745,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
           if (g == 0) part[(hn * 256 + rl) * 4 + wn] = sq;
         }
       }
+      if constexpr (FP8) load_rope();
       CA_GSTAMP(4);
       __syncthreads();
       // every load of this epilogue has been issued: wait for them HERE, once, through the builtin.  Otherwise hipcc
