@@ -81,7 +81,8 @@ if "--no-time" not in sys.argv:
         con.append(ops.Attn(qs[cj], att[cj], ks[cj], vs[cj], ks[ij], vs[ij], out_f32=att32[cj]))
         main.append(ops.Attn(qs[tj], att[tj], ks[tj], vs[tj], ks[ij], vs[ij], q1=qs[ij], out1=att[ij]))
     fl = B * 4.0 * (T + Li) ** 2 * 128 * nh
-    for name, probs in (("5 items, main only", main), ("5 items, concept + main", con + main), ("concept only", con)):
+    for name, probs in (("5 items, main only", main), ("5 items, concept + main", con + main),
+                        ("5 items, main + concept", main + con), ("concept only", con)):
         t = timeit(lambda: ops.attention(probs, nh, q_prescaled=True))
         print(f"{name:28s} {t*1e6:8.1f} us   {fl/t/1e12 if 'only' != name[-4:] or 'main' in name else 0:7.1f} TF/s",
               flush=True)
