@@ -18,16 +18,24 @@ using namespace ca_attn_detail;
 // hand-owned AGPRs, the scores / probabilities, -reference and the packed P fragments in compiler-allocated VGPRs
 // (an MFMA's C and D share a register class, A and B are free; v_exp_f32 cannot read AGPRs).  Every hot
 // instruction is its own `asm volatile` statement: hipcc keeps volatile asm statements in program order, so the
-// stream below IS the schedule -- a tile is 64 MFMAs with the LDS reads, the exponentials, the row-sum adds and the
-// bf16 packs placed in the gaps between them by tools/gen_attn4_schedule.py (ca_attn4_sched.inc):
-//     slots  0..31  S(t+1) = K(t+1) Q^T   beside  the first half of softmax(t+1), the V(t) reads, the K(t+1/t+2) reads
-//     slots 32..63  O^T += V(t)^T P(t)^T  beside  the second half of softmax(t+1) and the packs of P(t+1)
+// stream below IS the schedule -- a tile is 64 MFMAs with the LDS reads, the LDS-DMA pieces, the exponentials, the
+// row-sum adds and the bf16 packs placed in the gaps between them by tools/gen_attn4_schedule.py (ca_attn4_sched.inc;
+// the generator asserts its placement rules, build.py audits the emitted code for the hazards hipcc does not pad):
+//     slots  0..31  S(t+1) = K(t+1) Q^T, the two query blocks' chains interleaved (no MFMA waits for its predecessor)
+//     slots 32..63  O^T += V(t)^T P(t)^T
+//     gaps   1..15  (odd) the wave's 4 + 4 LDS-DMA pieces of K(t+3) / V(t+1): buffer descriptor + scalar tile offset
+//     gaps   2..32  (even) the K(t+1) key-block-1 and K(t+2) key-block-0 fragment reads; 17..49 (odd) the V(t) reads
+//     gaps  16..63 and 0..15 of the NEXT iteration: one exponential of S(t+1) and one row-sum add each; the packs of
+//                   P(t+1) behind the last P.V MFMA that reads the fragment they overwrite
 // K/V tiles arrive by LDS-DMA into 3-slot rings (K three tiles ahead: its first fragments are read one tile before
-// their MFMAs; V one tile ahead), one barrier per tile.  The softmax reference of a row is the maximum of tile 0 and
-// is kept (see ca_attn_kernel); there is no per-tile check: a row sum that left the safe range shows in the final
-// sums, and the workgroup then recomputes its rows the classical way (running maximum, rescale per tile).
+// their MFMAs; V one tile ahead), one barrier per tile; the per-tile bookkeeping is a compare per matrix against the
+// index of the next tile "event" (segment change, ragged / straddling / missing tile).  The softmax reference of a row
+// is the maximum of tile 0 and is kept (see ca_attn_kernel); there is no per-tile check: a row sum that left the safe
+// range shows in the final sums, and the workgroup then recomputes its rows the classical way (running maximum,
+// rescale per tile).
 // The two waves of a SIMD in ca_attn_kernel run in lockstep (same program, one barrier per tile): per tile the matrix
-// pipe idles while both exponentiate.  Here the single wave's own stream keeps it fed.
+// pipe idles while both exponentiate.  Here the single wave's own stream keeps it fed (2 265
+// cycles per tile for 2 048 of MFMA issue).
 #define CA_A4_HELPERS
 #include "ca_attn4_sched.inc"
 #undef CA_A4_HELPERS
