@@ -114,10 +114,12 @@ def stub_main(args):
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, "cpu")
     ok = all(bool((allm[j] == float(j)).all()) for j in range(n_timed))
+    evidence = D.collective_evidence("cpu")   # the same record the real line carries as "collective"
     if rank == 0:
         print(json.dumps({"metric": "STUB (launcher test, no GPU work)", "value": n_timed * C / max(elapsed, 1e-9),
                           "workload": args.workload,
                           "collective": "all_reduce" if args.workload == "sweep" else "all_gather",
+                          "collective_evidence": evidence,
                           "unit": "stub-items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / args.steps * 1e3, "gathered_in_item_order": ok,
                           "data": "stub"}), flush=True)
@@ -178,6 +180,17 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-launch HIP-event timing of the GEMM kernel (roofline.achieved then "
                          "comes from whole-path FLOPs / wall time)")
+    ap.add_argument("--no-solo-check", action="store_true",
+                    help="skip the single-item re-run of the last timed item after the timed region "
+                         "(batched_equals_single is then null); profiling runs use it so that every launch of the "
+                         "process has the batched shape")
+    ap.add_argument("--no-block-timing", action="store_true",
+                    help="skip the extra, untimed forward that times the 19 double blocks (concept_attention_block)")
+    ap.add_argument("--profile-mode", action="store_true",
+                    help="what tools/profile_round.py runs under rocprofv3: --no-solo-check --no-block-timing "
+                         "--no-cpu-baseline --no-kernel-timing, so the process holds exactly 1 warm-up group + the timed "
+                         "groups of --batch items and every launch in the trace has the timed shape; launches are counted "
+                         "per kernel kind (no events) and reported as launch_counts")
     ap.add_argument("--stub-fail-rank", type=int, default=None,
                     help="TEST ONLY (with --stub-workload): this rank exits non-zero after the rendezvous")
     ap.add_argument("--stub-workload", action="store_true",
@@ -186,6 +199,8 @@ def main():
     args = ap.parse_args()
     if args.concepts is None:
         args.concepts = 2 if args.workload == "encode" else 4
+    if args.profile_mode:
+        args.no_solo_check = args.no_block_timing = args.no_cpu_baseline = args.no_kernel_timing = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
@@ -299,9 +314,22 @@ def main():
     head, last = timed_items[:-n_last], timed_items[-n_last:]
     if head:
         local_maps += run_many(head, args.streams, args.batch)
+    launch_counts = {}
+
+    def count_gemm(arr, tile, launch):   # --profile-mode: no events, only how many calls of which tile kind were made
+        launch_counts[f"gemm_tile_{tile}"] = launch_counts.get(f"gemm_tile_{tile}", 0) + 1
+        launch()
+
+    def count_attn(arr, num_heads, launch):
+        launch_counts["attn"] = launch_counts.get("attn", 0) + 1
+        launch()
+
     if not args.no_kernel_timing:
         ops.set_gemm_hook(hook)
         ops.set_attn_hook(attn_hook)
+    elif args.profile_mode:
+        ops.set_gemm_hook(count_gemm)
+        ops.set_attn_hook(count_attn)
     local_maps += run_many(last, 1, args.batch)
     ops.set_gemm_hook(None)
     ops.set_attn_hook(None)
@@ -320,11 +348,13 @@ def main():
     elapsed = D.max_over_ranks(elapsed, dev)
 
     calls = n_timed
+    # evidence that the job's collectives ran over `world` ranks on `world` different devices (rank 0 prints it)
+    collective = D.collective_evidence(dev) if world > 1 else None
 
     # ---- the "concept-attention block" figure of BASELINE.json: average duration of a double block
     # (HIP events around each of the 19 block calls of one extra, untimed forward; rank 0 only)
     block = None
-    if rank == 0:
+    if rank == 0 and not args.no_block_timing:
         m = pipe.model
         nb = max(1, min(args.batch, len(timed_items)))   # the forward holds --batch items; times are per item
         i0 = {k: torch.cat([inputs[j][k] for j in timed_items[:nb]], 0) for k in ("latent", "txt", "vec", "concepts")}
@@ -359,14 +389,25 @@ def main():
                  "mfma_frac": dbl_flops / med / 1e6 / MFMA_BF16_PEAK_TFLOPS}
     if not bool(torch.isfinite(all_maps).all().item()):
         raise SystemExit("bench: non-finite heat maps")
+    # the softmax over the concepts makes every patch's maps sum to 1 (concept_attention_pipeline.py:64-65); cheap, and
+    # it catches a forward that produced finite garbage
+    col = all_maps.float().sum(dim=-3)
+    if float((col - 1.0).abs().max().item()) > 1e-3:
+        raise SystemExit(f"bench: heat maps are not normalised over the concepts (max |sum - 1| = "
+                         f"{float((col - 1.0).abs().max().item()):.3e})")
     # ---- the batched forward against the reference's unit of work (ONE item per call,
     # concept_attention_pipeline.py:115-202): the last timed item of rank 0 again, alone, outside the timed region;
     # its maps must equal the ones the batched group produced bit for bit
     batched_equals_single = None
-    if rank == 0 and timed_items:
+    if rank == 0 and timed_items and not args.no_solo_check:
         solo = run_item(timed_items[-1])
         torch.cuda.synchronize()
         batched_equals_single = bool(torch.equal(solo, local_maps[-1]))
+        if not batched_equals_single and args.precision == "bf16":
+            # per item the batched forward is specified to be bit-identical to a single-item call (same MFMA, same
+            # k order); a line whose value comes from a forward that is not must not exist
+            raise SystemExit("bench: the batched forward differs from the single-item call of the same item "
+                             f"(max |diff| = {float((solo - local_maps[-1]).abs().max().item()):.3e})")
 
     if rank == 0:
         if wl == "generate":
@@ -415,6 +456,11 @@ def main():
                 names[5] = "ca_gemm_pp_kernel<2,2,fp8> (256x256x128 ping-pong, e4m3)"
             roof.update(kernel=names.get(tile, str(tile)), launches=n, avg_launch_us=sec / n * 1e6,
                         flops_per_launch=fl / n, achieved=fl / sec / 1e12,
+                        flops_are="executed 2*M*N*K of every problem of the call, which includes the low-plane q "
+                                  "projection of the captured layers (about 0.55 % above the algorithmic count)",
+                        recompute_from_csv="profiles/rNN_rocprofv3_kernel_stats.csv: avg_launch_us ~= (TotalDurationNs["
+                                           "ca_gemm_pp_kernel<2,2>] + TotalDurationNs[ca_gemm_thin_kernel<2>]) / Calls["
+                                           "ca_gemm_pp_kernel<2,2>] / 1e3 (HIP events add the ~5 us drain per call)",
                         timed_on=f"last group of {n_last} work items of rank 0 (one forward per diffusion step)",
                         launch_is="one ca_gemm_bf16 call: the ping-pong launch plus, for a thin last row tile, "
                                   "its thin-row launch (ca_gemm_thin_kernel); rocprofv3 lists the two kernels separately",
@@ -442,16 +488,26 @@ def main():
             pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]
             pmc_doc = json.load(open(pmc_file))
             pmc = pmc_doc["kernels"]
+            # a per-launch average is only this launch's traffic if every profiled launch had the timed shape:
+            # the file states its launch mix (tools/profile_round.py) and one of another mix is refused
+            mix = pmc_doc.get("launch_mix") or {}
+            same_mix = (mix.get("items_per_forward") == args.batch and mix.get("workload") == wl
+                        and mix.get("model") == args.model and mix.get("concepts") == C
+                        and mix.get("size") == args.size and mix.get("only_batched_launches") is True)
             key = roof.get("kernel", "").split(" ")[0]
-            if key in pmc and not fp8:
+            if not same_mix:
+                roof["traffic_source"] = (f"profiles/{os.path.basename(pmc_file)} holds launch_mix {mix or 'none'}, not "
+                                          "this run's shape: traffic not reported")
+            elif key in pmc and not fp8:
                 roof["traffic"] = pmc[key]["bytes_per_launch"]
                 roof["traffic_source"] = (f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                          f"passes of this command at {pmc_doc.get('git_head', 'an earlier commit')}; "
-                                          "counters cannot be read from inside the process)")
+                                          f"passes of `{pmc_doc.get('command', 'bench.py --profile-mode')}` at "
+                                          f"{pmc_doc.get('git_head', 'an earlier commit')}: every launch of that process is a "
+                                          f"{args.batch}-item launch; counters cannot be read from inside the process)")
             akey = roof_attn["kernel"].split(" ")[0] if roof_attn is not None else None
-            if akey in pmc and not fp8:
+            if same_mix and akey in pmc and not fp8:
                 roof_attn["traffic"] = pmc[akey]["bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["path_achieved"] = path_tflops
@@ -478,6 +534,8 @@ def main():
                                         f"{layer_indices} (the heat-map layers stay bf16)"} if fp8 else {})},
             "calls_per_s": calls / elapsed,
             "batched_equals_single": batched_equals_single,
+            **({"collective": collective} if collective is not None else {}),
+            **({"launch_counts": launch_counts} if args.profile_mode else {}),
             "roofline": roof,
             "roofline_attention": roof_attn,
             "concept_attention_block": block,

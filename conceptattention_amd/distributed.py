@@ -81,6 +81,33 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def collective_evidence(device) -> dict | None:
+    """What a reader of the bench line needs to believe that N ranks took part: the backend, how many ranks an
+    all_reduce(sum) of 1 saw, and the device every rank ran on (all_gather of its index and its PCI bus id), so that
+    a job whose ranks all sat on one GPU, or whose group is smaller than --gpus, shows in its own JSON."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return None
+    world, backend = dist.get_world_size(), dist.get_backend()
+    on = torch.device(device) if backend == "nccl" else torch.device("cpu")
+    one = torch.ones(1, dtype=torch.int64, device=on)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    dev = torch.device(device)
+    idx = dev.index if dev.type == "cuda" and dev.index is not None else -1
+    bus = -1
+    if dev.type == "cuda" and torch.cuda.is_available():
+        try:
+            bus = int(torch.cuda.get_device_properties(dev).pci_bus_id)
+        except (AttributeError, RuntimeError):
+            bus = -1
+    mine = torch.tensor([idx, bus], dtype=torch.int64, device=on)
+    out = torch.empty(world * 2, dtype=torch.int64, device=on)
+    dist.all_gather_into_tensor(out, mine)
+    rows = out.view(world, 2).cpu().tolist()
+    return {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend,
+            "ranks_seen": int(one.item()), "devices": [r[0] for r in rows], "pci_bus_ids": [r[1] for r in rows],
+            "distinct_devices": len({tuple(r) for r in rows})}
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

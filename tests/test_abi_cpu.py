@@ -39,6 +39,50 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(L.ModSegment) == 24 and ctypes.sizeof(L.NormSegment) == 24
 
 
+def _header_struct_fields(name):
+    """(type, field) pairs of a `typedef struct { ... } name;` in include/conceptattn.h, in declaration order."""
+    text = open(os.path.join(ROOT, "include", "conceptattn.h")).read()
+    body = re.search(r"typedef struct \{(.*?)\}\s*" + name + r"\s*;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r"(?:const\s+)?(void|float|int32_t)\s*(\*?)\s*(.*)$", decl, re.S)
+        assert m, decl
+        ctype = "ptr" if m.group(2) or m.group(3).lstrip().startswith("*") else m.group(1)
+        for f in m.group(3).split(","):
+            out.append((ctype, f.strip().lstrip("*").strip()))
+    return out
+
+
+_CT = {"ptr": ctypes.c_void_p, "int32_t": ctypes.c_int32, "float": ctypes.c_float}
+
+
+def test_binding_fields_match_header_field_for_field():
+    """Names, order and C types of ca_gemm_problem in the header == conceptattention_amd/_lib.py's ctypes struct."""
+    hdr = _header_struct_fields("ca_gemm_problem")
+    assert [f for _, f in hdr] == [f for f, _ in L.GemmProblem._fields_]
+    assert [_CT[t] for t, _ in hdr] == [t for _, t in L.GemmProblem._fields_]
+
+
+def test_integration_md_stub_is_the_current_abi():
+    """INTEGRATION.md section B shows the ctypes stub a maintainer copies; a stale copy hands the library a struct
+    it reads past (round 3's document was two fields short).  Parse the struct out of the document and compare names,
+    order, types and sizeof with the binding and the header."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"class GemmProblem\(C\.Structure\):.*?_fields_ = \[(.*?)\]\s*(?:#[^\n]*)?\n\n", doc, re.S).group(1)
+    fields = re.findall(r'\("(\w+)",\s*C\.(c_\w+)\)', block)
+    assert fields, "no fields parsed from INTEGRATION.md"
+    assert [(f, getattr(ctypes, t)) for f, t in fields] == list(L.GemmProblem._fields_)
+    Doc = type("Doc", (ctypes.Structure,), {"_fields_": [(f, getattr(ctypes, t)) for f, t in fields]})
+    assert ctypes.sizeof(Doc) == ctypes.sizeof(L.GemmProblem)
+    assert [f for f, _ in fields] == [f for _, f in _header_struct_fields("ca_gemm_problem")]
+    m = re.search(r"ABI version (\d+)", doc)
+    assert m and int(m.group(1)) == L.CA_VERSION
+
+
 def test_argument_rejection_needs_no_gpu(lib):
     assert lib.ca_gemm_bf16(None, 1, 0, None) == -1
     assert b"n_problems" in lib.ca_last_error() or b"ca_gemm" in lib.ca_last_error()

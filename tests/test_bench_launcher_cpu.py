@@ -28,6 +28,9 @@ def test_self_launch_two_ranks_prints_one_json_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["gathered_in_item_order"] is True
     assert out["data"] == "stub" and out["metric"].startswith("STUB")
+    # the record that lets a reader of the line verify the group: an all_reduce(sum) of 1 over the ranks, one entry per rank
+    ev = out["collective_evidence"]
+    assert ev["backend"] == "gloo" and ev["ranks_seen"] == 2 and len(ev["devices"]) == 2
 
 
 def test_self_launch_propagates_child_failure():

@@ -1,7 +1,7 @@
 """Build profiles/rNN_pmc_hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- python3 bench.py \\
-        --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing
+        --steps 5 --warmup 1 --streams 1 --profile-mode
     rocprofv3 --pmc WRITE_SIZE ... -d gpurun_out/pmc_WRITE_SIZE -- (same command)
     python tools/pmc_hbm_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE out.json
 
@@ -41,7 +41,8 @@ def collect(d, counter):
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 out = {"method": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --kernel-trace --output-format csv -- "
-                 "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing; per-launch averages; "
+                 "the bench command tools/profile_round.py records next to this text as `command`; per-launch averages over the "
+                 "launches `launch_mix` describes; "
                  "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide coalesced read "
                  "stream, MI355X_MICROARCH.md 'HBM'; calibrated on ca_ln_modulate_kernel: algorithmic read 26.8 MB)",
        "note": "FETCH_SIZE counts the L2's fabric-side requests, Infinity-Cache hits included, so this is an upper "

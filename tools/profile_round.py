@@ -4,8 +4,12 @@
     python tools/profile_round.py --round 2            # in the build container: drives ONE gpurun call
     python tools/profile_round.py --on-box --round 2   # what that call executes on the GPU box
 
-On the box, for the exact bench command (`python3 bench.py --steps 5 --warmup 1 --streams 1 --no-cpu-baseline
---no-kernel-timing`: one warm-up group and one timed group of 5 work items, one stream, so every launch has the batched shape and per-kernel durations are exclusive):
+On the box, for the exact bench command (`python3 bench.py --steps 5 --warmup 1 --streams 1 --profile-mode`: one
+warm-up group and one timed group of 5 work items on one stream and NOTHING else -- no single-item re-run, no
+block-timing forward, no per-launch events -- so every launch in the trace is a 5-item launch, the two groups hold the
+same launch list, and a kernel's AverageNs is the average over one 5-item call's launches, which is what bench.py's
+`roofline.avg_launch_us` measures with HIP events; the launch counts bench.py reports for ONE group are checked against
+the trace: Calls == 2 x that):
   1. rocprofv3 --kernel-trace --stats                       -> profiles/rNN_rocprofv3_kernel_stats.csv
   2. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace
                                                             -> profiles/rNN_pmc_mfma_busy.json
@@ -24,8 +28,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = ["python3", "bench.py", "--steps", "5", "--warmup", "1", "--streams", "1", "--no-cpu-baseline",
-         "--no-kernel-timing"]
+BENCH = ["python3", "bench.py", "--steps", "5", "--warmup", "1", "--streams", "1", "--profile-mode"]
+LAUNCH_MIX = {"items_per_forward": 5, "workload": "generate", "model": "flux-schnell", "concepts": 4, "size": 1024,
+              "groups_in_process": 2, "only_batched_launches": True}
 
 
 def sh(cmd, **kw):
@@ -46,8 +51,24 @@ def on_box(rnd: int, head: str):
        stdout=open(os.path.join(out, "trace.log"), "w"), stderr=subprocess.STDOUT, check=True)
     stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
     lines = open(stats[0]).read().splitlines()
+    # bench.py --profile-mode counted the calls of ONE group; the trace holds the warm-up group and the timed group
+    trace_log = open(os.path.join(out, "trace.log")).read()
+    counts = json.loads([l for l in trace_log.splitlines() if l.startswith("{")][-1])["launch_counts"]
+    import csv as _csv
+    calls = {}
+    for r in _csv.DictReader(lines):
+        for key, pat in (("gemm_tile_5", "ca_gemm_pp_kernel<2, 2, false>"), ("attn", "ca_attn4_kernel")):
+            if pat in r["Name"]:
+                calls[key] = int(r["Calls"])
+    mix = dict(LAUNCH_MIX, calls_per_group=counts, calls_in_trace=calls)
+    for key, n in calls.items():
+        if n != 2 * counts.get(key, -1):   # bench.py then refuses the traffic file (only_batched_launches False)
+            print(f"profile_round: the trace holds {n} launches of {key}, two 5-item groups make "
+                  f"{2 * counts.get(key, -1)}: some launch in the process does not have the timed shape", flush=True)
+            mix["only_batched_launches"] = False
     with open(os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"), "w") as f:
-        f.write(f"# git_head {head}; command: rocprofv3 --kernel-trace --stats -- {' '.join(BENCH)}\n")
+        f.write(f"# git_head {head}; command: rocprofv3 --kernel-trace --stats -- {' '.join(BENCH)}; launch_mix "
+                f"{json.dumps(mix)}\n")
         f.write("\n".join(lines[:40]) + "\n")
     # 2. MFMA busy
     d = os.path.join(out, "pmc_mfma")
@@ -57,7 +78,7 @@ def on_box(rnd: int, head: str):
     j = os.path.join(out, f"{tag}_pmc_mfma_busy.json")
     sh([sys.executable, "tools/pmc_summary.py", d, j], check=True)
     doc = {"git_head": head, "command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE "
-           "--kernel-trace -- " + " ".join(BENCH), "kernels": json.load(open(j))}
+           "--kernel-trace -- " + " ".join(BENCH), "launch_mix": mix, "kernels": json.load(open(j))}
     json.dump(doc, open(j, "w"), indent=1, sort_keys=True)
     # 3. HBM-side traffic, one counter per pass
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -69,6 +90,13 @@ def on_box(rnd: int, head: str):
         os.path.join(out, "pmc_WRITE_SIZE"), j], check=True)
     doc = json.load(open(j))
     doc["git_head"] = head
+    doc["command"] = " ".join(BENCH)
+    doc["launch_mix"] = mix
+    n_pp = doc["kernels"].get("ca_gemm_pp_kernel<2,2>", {}).get("launches")
+    if n_pp != calls.get("gemm_tile_5"):
+        print(f"profile_round: the counter pass saw {n_pp} ca_gemm_pp_kernel<2,2> launches, the trace "
+              f"{calls.get('gemm_tile_5')}", flush=True)
+        doc["launch_mix"] = dict(mix, only_batched_launches=False)
     json.dump(doc, open(j, "w"), indent=1)
     shutil.copy(j, os.path.join(ROOT, "profiles", os.path.basename(j)))  # step 4 reads roofline.traffic from it
     # 4. the default, un-profiled bench line (groups of 5 work items, per-launch HIP-event timing on the last group)
