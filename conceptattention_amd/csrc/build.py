@@ -42,6 +42,7 @@ def audit_attn4(asm_path: str) -> None:
                  re.search(r"\bm0\b", line.split(";")[0])):   # (M0: the tile loop's LDS-DMA writes it without saving it)
             bad.append(line.strip())
     bad += audit_sgpr_hazards(text)
+    bad += audit_mfma_result_hazards(text)
     m = re.search(r"\.vgpr_spill_count:\s*(\d+)", text)
     scratch = re.search(r"\.private_segment_fixed_size:\s*(\d+)", text)
     if bad or (m and int(m.group(1))) or (scratch and int(scratch.group(1))):
@@ -116,6 +117,136 @@ def audit_sgpr_hazards(text: str) -> list:
         hist.append((ws, valu_sgpr_write, re.search(r"\bm0\b", first) is not None, code))
         hist = hist[-12:]
     return bad
+
+
+def _regs(tok: str) -> set:
+    """('v' | 'a', n) for every vector / accumulator register an operand string names."""
+    import re
+    out = set()
+    for c, a, b in re.findall(r"\b([va])\[(\d+):(\d+)\]", tok):
+        out |= {(c, i) for i in range(int(a), int(b) + 1)}
+    out |= {(c, int(x)) for c, x in re.findall(r"\b([va])(\d+)\b", tok)}
+    return out
+
+
+def _mfma_passes(op: str) -> int:
+    # gfx950: v_mfma_f32_32x32x16_{bf16,f16} and the 16x16x128 f8f6f4 forms hold the matrix pipe for 8 passes of 4
+    # cycles, the 16x16x32 forms for 4; anything unknown is taken as the longest (16)
+    if "32x32x16" in op or "16x16x128" in op:
+        return 8
+    if "16x16x32" in op:
+        return 4
+    return 16
+
+
+def audit_mfma_result_hazards(text: str) -> list:
+    """The hazard the other audits do not see: the RESULT of an MFMA that sits inside an asm statement, touched too early.
+    gfx950 does not interlock it and hipcc pads nothing around an instruction it cannot see: a register written by an
+    N-pass MFMA may be read or written by a VALU / LDS / VMEM instruction, or read by another MFMA as A or B, only
+    N + 3 wait states after the MFMA issued (8 passes: 11).  An MFMA that accumulates onto it (C = D = the same
+    tuple) is interlocked by the hardware.
+
+    Time model (one unit = one wait state = one issue slot of the wave): every instruction takes 1, `s_nop N` N + 1,
+    and an MFMA issues no earlier than N after the previous MFMA issued (one matrix pipe per SIMD) -- which is what
+    lets the generated stream read a score two MFMA slots after the chain's last MFMA.  Checked for EVERY instruction,
+    inside or outside #ASMSTART (a copy or a re-ordered instruction hipcc places between two asm statements is exactly
+    the failure of commit 863ff6e).  Control flow: the scan is linear in layout order (fall-through), and the state at
+    every branch is carried to the branch target as well -- the R = 2 -> R = 0 back-edge of the tile loop included.
+
+    Second rule, for the generated stream (statements marked `; a4s` by tools/gen_attn4_schedule.py): between two marked
+    statements of one basic block hipcc may place scalar instructions and s_nop only; any vector, LDS or memory
+    instruction there means it moved or copied a register the schedule owns."""
+    import re
+    ins = []          # (op, args, inside_asm, marked, raw)
+    labels = {}
+    inside = marked = False
+    for line in text.split("\n"):
+        if "#ASMSTART" in line:
+            inside, marked = True, False
+            continue
+        if "#ASMEND" in line:
+            inside = False
+            continue
+        if inside and "; a4s" in line:
+            marked = True
+        code = line.split(";")[0].strip()
+        if not code or code.startswith("."):
+            m = re.match(r"^(\.?[A-Za-z_][\w.$]*):", code)
+            if m:
+                labels[m.group(1)] = len(ins)
+                ins.append(("label", m.group(1), False, False, code))
+            continue
+        m = re.match(r"^([A-Za-z_][\w.$]*):$", code)
+        if m:
+            labels[m.group(1)] = len(ins)
+            ins.append(("label", m.group(1), False, False, code))
+            continue
+        op = code.split()[0]
+        ins.append((op, code[len(op):], inside, inside and marked, code))
+    bad = []
+
+    def scan(start, t, pipe_free, pending, limit, snapshots):
+        """pending: list of (ready_time, regs, text).  Returns nothing; appends to bad."""
+        n = 0
+        for i in range(start, len(ins)):
+            op, args, in_asm, _, raw = ins[i]
+            if op == "label":
+                continue
+            if limit is not None:
+                n += 1
+                if n > limit or not any(r > t for r, _, _ in pending):
+                    return
+            pending = [p for p in pending if p[0] > t]
+            if op == "s_nop":
+                t += int(args.split()[0], 0) + 1
+                continue
+            if op.startswith(("s_endpgm",)):
+                return
+            if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+                parts = [x.strip() for x in args.split(",")]
+                d, a, b, c = (_regs(parts[0]), _regs(parts[1]), _regs(parts[2]), _regs(parts[3]) if len(parts) > 3 else set())
+                t = max(t, pipe_free)
+                for ready, regs, txt in pending:
+                    if ready > t and ((a | b) & regs or ((c | d) & regs and not (c == regs and d == regs))):
+                        bad.append(f"{txt} -> {raw} (MFMA result used {ready - t} wait states early)")
+                passes = _mfma_passes(op)
+                pipe_free = t + passes
+                if in_asm:   # hipcc knows (and pads) the MFMAs it emits itself
+                    pending.append((t + 1 + passes + 3, d, raw))
+                t += 1
+                continue
+            touched = _regs(args)
+            if touched:
+                for ready, regs, txt in pending:
+                    if ready > t and touched & regs:
+                        bad.append(f"{txt} -> {raw} (MFMA result used {ready - t} wait states early)")
+            if snapshots is not None and op.startswith(("s_cbranch", "s_branch")):
+                snapshots.append((args.strip(), t + 1, pipe_free, list(pending)))
+            t += 1
+
+    snaps = []
+    scan(0, 0, 0, [], None, snaps)
+    for target, t, pipe_free, pending in snaps:
+        if target in labels and any(r > t for r, _, _ in pending):
+            scan(labels[target], t, pipe_free, pending, 64, None)
+    # ---- nothing but scalar instructions between two stream statements of one basic block
+    prev_marked = False
+    between = []
+    for op, args, in_asm, mk, raw in ins:
+        if op == "label" or op.startswith(("s_cbranch", "s_branch")):
+            prev_marked, between = False, []
+            continue
+        if mk:
+            if prev_marked:
+                bad += [f"{r} (compiler instruction inside the generated stream)" for r in between]
+            prev_marked, between = True, []
+            continue
+        if in_asm:          # an unmarked asm statement (helpers): ends the stream region
+            prev_marked, between = False, []
+            continue
+        if prev_marked and op.startswith(("v_", "ds_", "buffer_", "global_", "scratch_", "flat_")):
+            between.append(raw)
+    return sorted(set(bad))
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

@@ -390,6 +390,8 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   L.num_heads = num_heads;
   L.n_problems = n_problems;
   L.scale_log2 = scale * 1.4426950408889634f;
+  static const bool no_reref = getenv("CA_ATTN_REREF") && atoi(getenv("CA_ATTN_REREF")) == 0;
+  L.flags = no_reref ? 1 : 0;
   const int hx = (num_heads + 7) / 8;  // heads per XCD group
   int total = 0;
   for (int i = 0; i < n_problems; ++i) {
@@ -467,4 +469,12 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
     return CA_ERR_LAUNCH;
   }
   return CA_OK;
+}
+
+extern "C" int ca_attn_stats(unsigned long long *counters, int32_t reset) {
+  if (!counters) {
+    ca_set_error("ca_attn_stats: null pointer");
+    return CA_ERR_ARG;
+  }
+  return ca_attn4_read_counters(counters, reset);
 }

@@ -30,9 +30,12 @@ using namespace ca_attn_detail;
 // K/V tiles arrive by LDS-DMA into 3-slot rings (K three tiles ahead: its first fragments are read one tile before
 // their MFMAs; V one tile ahead), one barrier per tile; the per-tile bookkeeping is a compare per matrix against the
 // index of the next tile "event" (segment change, ragged / straddling / missing tile).  The softmax reference of a row
-// is the maximum of tile 0 and is kept (see ca_attn_kernel); there is no per-tile check: a row sum that left the safe
-// range shows in the final sums, and the workgroup then recomputes its rows the classical way (running maximum,
-// rescale per tile).
+// is the maximum of tile 0 and is kept (see ca_attn_kernel) for as long as the row sums stay small: every third tile
+// one compare looks at the wave's running sums, and a wave that finds one above 2^20 RE-REFERENCES in place
+// (rereference(): every row's reference moves up by the exponent of its sum, O / l / the pending probabilities are
+// scaled by the exact power of two; no key is visited twice).  What is left for the final check is a sum that
+// overflowed between two compares (a score more than ~80 octaves above the running reference, inf / NaN inputs): the
+// workgroup then recomputes its rows the classical way (running maximum, rescale per tile).
 // The two waves of a SIMD in ca_attn_kernel run in lockstep (same program, one barrier per tile): per tile the matrix
 // pipe idles while both exponentiate.  Here the single wave's own stream keeps it fed (2 265
 // cycles per tile for 2 048 of MFMA issue).
@@ -47,8 +50,14 @@ constexpr int FLAG_OFF = 2 * SLOTS * TILE_BYTES;           // the "recompute" fl
 constexpr int DUMP_OFF = FLAG_OFF + 1024;                  // 16 KiB nobody reads: where the tile loop's LDS-DMA pieces land
                                                            // when there is no tile for them (they then re-read a valid one)
 constexpr int LDS_BYTES = DUMP_OFF + TILE_BYTES;
-constexpr float L_LIMIT = 1152921504606846976.0f;          // 2^60
+constexpr float L_LIMIT = 1267650600228229401496703205376.0f;   // 2^100: a finite row sum below this is exact enough to
+                                                                // divide by (O <= l max|v| stays far from fp32's 2^128)
+constexpr float REREF_ABOVE = 1048576.0f;                  // 2^20: running row sum that triggers the in-place re-reference
 }  // namespace a4
+
+// diagnostic counters (ca_attn_stats): [0] workgroups that went through the classical recomputation, [1] in-place
+// re-reference events (per wave).  Written by the rare paths only.
+__device__ unsigned long long ca_attn4_counters[2];
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -188,6 +197,16 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
       EVV = dma_event(t + 1, ((R_) + 1) % 3, true, (uint32_t)(a4::V_BASE + (((R_) + 1) % 3) * TILE_BYTES), DSV, SOV, LWV); \
   } while (0)
 #define CA_A4_ADVANCE() do { SOK += tile_step; SOV += tile_step; } while (0)
+  // one compare per three tiles: has any partial row sum of this wave left the comfortable range?
+  const bool reref_on = active && !(L.flags & 1);
+#define CA_A4_REREF_CHECK()                                                                                            \
+  do {                                                                                                                 \
+    /* (the sums are >= 0, so their bit patterns order like the values; a NaN's pattern is above every finite one) */ \
+    if (reref_on && __builtin_expect(__builtin_amdgcn_ballot_w64(                                                      \
+                        max(max(__float_as_int(l0), __float_as_int(l0b)),                                              \
+                            max(__float_as_int(l1), __float_as_int(l1b))) > __float_as_int(a4::REREF_ABOVE)) != 0, 0)) \
+      rereference();                                                                                                   \
+  } while (0)
   auto stage_pieces = [&](uint32_t kdst_off, uint32_t vdst_off) {   // the same 8 pieces from a wave that computes nothing
     auto piece = [&](const i32x4 &ds, uint32_t so, uint32_t off, uint32_t dst) {   // (its query rows do not exist)
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
@@ -265,6 +284,32 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
     }
     x0 = fmaxf(x0, __shfl_xor(x0, 32));
     x1 = fmaxf(x1, __shfl_xor(x1, 32));
+  };
+  // In-place re-reference (rare; top of an iteration, see the state described at "tile 0" below): row i's reference
+  // goes up by e_i = floor(log2(row sum so far)) >= 0.  Everything that carries the old reference is scaled by the
+  // exact power of two 2^-e_i -- O^T, the four partial sums, the exponentiated scores of the tile in flight (S00,
+  // S01, S10; their packed fragments are re-packed) -- or shifted by e_i (S11: still raw score - reference; NM).
+  // Per-row and a function of the row's own keys only, so an item's bits do not depend on the launch it shares.
+  auto rereference = [&]() {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(S00), "+v"(S01), "+v"(S10), "+v"(S11));   // MFMA results -> VALU
+    float t0 = l0 + l0b, t1 = l1 + l1b;
+    t0 += __shfl_xor(t0, 32), t1 += __shfl_xor(t1, 32);
+    // exponent field (t >= 0; inf / NaN -> 255: clamped, the final check then sends the workgroup to the recomputation)
+    const int e0 = min(max(((__float_as_int(t0) >> 23) & 0xff) - 127, 0), 126);
+    const int e1 = min(max(((__float_as_int(t1) >> 23) & 0xff) - 127, 0), 126);
+    const float f0 = __int_as_float((127 - e0) << 23), f1 = __int_as_float((127 - e1) << 23);
+    const float d0 = (float)e0, d1 = (float)e1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S00[r] *= f0, S10[r] *= f0, S01[r] *= f1, S11[r] -= d1;
+      NM0[r] -= d0, NM1[r] -= d1;
+    }
+    l0 *= f0, l0b *= f0, l1 *= f1, l1b *= f1;
+    pack_one(P000, S00, 0), pack_one(P001, S00, 8), pack_one(P010, S01, 0), pack_one(P011, S01, 8);
+    pack_one(P100, S10, 0);
+    CA_A4_SCALE_O(f0, f1);
+    asm volatile("s_nop 7" : "+v"(NM0), "+v"(NM1), "+v"(P000), "+v"(P001), "+v"(P010), "+v"(P011), "+v"(P100));
+    if (lane == 0) atomicAdd(&ca_attn4_counters[1], 1ull);
   };
   auto set_reference = [&](float r0, float r1) {
     m0 = r0, m1 = r1;
@@ -361,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
 #endif
   int t = 0;
   while (t + 3 <= T) {
-    { constexpr int R = 0; (void)R; CA_A4_T(ts0); CA_A4_BOOKKEEPING(0); CA_A4_T(ts1);
+    { constexpr int R = 0; (void)R; CA_A4_T(ts0); CA_A4_BOOKKEEPING(0); CA_A4_REREF_CHECK(); CA_A4_T(ts1);
       if (active) {
 #define CA_A4_SCHEDULE
 #include "ca_attn4_sched.inc"
@@ -455,7 +500,9 @@ __global__ __launch_bounds__(256, 1) void ca_attn4_kernel(const AttnLaunch L) {
   if (active && __builtin_amdgcn_ballot_w64(!(l0 <= a4::L_LIMIT) || !(l1 <= a4::L_LIMIT)) != 0 && lane == 0) *flag = 1;
   drain_and_barrier();
   if (*flag) {
-    // classical online softmax, one tile at a time, nothing overlapped (rare: a score > 60 octaves above tile 0's max)
+    // classical online softmax, one tile at a time, nothing overlapped (rare: a row sum that overflowed between two
+    // re-reference checks, or inf / NaN inputs)
+    if (tid == 0) atomicAdd(&ca_attn4_counters[0], 1ull);
     CA_A4_ZERO_O();
     l0 = l1 = 0.f;
     m0 = m1 = -1e30f;
@@ -530,6 +577,19 @@ extern "C" int ca_debug_read_attn4(unsigned long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_a4_dbg), sizeof(unsigned long long) * 4 * 4 * 4096);
 }
 #endif
+
+int ca_attn4_read_counters(unsigned long long *out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_attn4_counters), 2 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) {
+    const unsigned long long z[2] = {0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(ca_attn4_counters), z, sizeof(z));
+  }
+  if (e != hipSuccess) {
+    ca_set_error("ca_attn_stats: %s", hipGetErrorString(e));
+    return CA_ERR_LAUNCH;
+  }
+  return CA_OK;
+}
 
 int ca_attn4_launch(const AttnLaunch &L, int total, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};

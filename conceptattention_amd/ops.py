@@ -215,6 +215,14 @@ def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] =
     L.check(lib.ca_attn_fwd_bf16(arr, len(problems), num_heads, scale, _stream()), "ca_attn_fwd_bf16")
 
 
+def attention_stats(reset: bool = False) -> dict:
+    """Counters of ca_attn4_kernel's rare softmax paths on the current device (blocking copy; diagnostics only)."""
+    import ctypes
+    c = (ctypes.c_ulonglong * 2)()
+    L.check(L.load().ca_attn_stats(c, int(reset)), "ca_attn_stats")
+    return {"recomputed_workgroups": int(c[0]), "rereference_events": int(c[1])}
+
+
 # Optional instrumentation used by bench.py: hook(problem_array, num_heads, launch) must call launch().
 _attn_hook = None
 

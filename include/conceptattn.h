@@ -28,8 +28,8 @@
 extern "C" {
 #endif
 
-#define CA_VERSION 121 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
-                          CA_ATTN_Q_PRESCALED; .1: ca_axpy_f32, ca_split_bf16 */
+#define CA_VERSION 122 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
+                          CA_ATTN_Q_PRESCALED; .1: ca_axpy_f32, ca_split_bf16; .2: ca_attn_stats */
 
 #define CA_OK 0
 #define CA_ERR_ARG (-1)    /* bad shape / null pointer / misalignment */
@@ -168,6 +168,12 @@ typedef struct {
 #define CA_ATTN_Q_PRESCALED 0.0f
 int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
                      float scale, ca_stream_t stream);
+/* Diagnostics of the pre-scaled-q kernel's two rare paths on the current device, since the last reset:
+ * counters[0] = workgroups whose rows were recomputed with a running maximum (a row sum overflowed: a score more
+ * than ~80 octaves above the running softmax reference, or inf / NaN inputs), counters[1] = in-place re-reference
+ * events (per wave: a running row sum passed 2^20 and the reference was moved up).  Both are 0 on the data the
+ * reference's synthetic weights produce.  A blocking device-to-host copy: not for the hot path; reset != 0 zeroes them. */
+int ca_attn_stats(unsigned long long *counters, int32_t reset);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (no affine, eps) followed by adaLN modulation:  out = (1 + scale) * LN(x) + shift

@@ -82,3 +82,66 @@ def test_build_audits_flag_the_three_hazards():
     assert any("v_cvt_pk_bf16_f32 v5" in b for b in build.audit_sgpr_hazards(valu))
     far = valu.replace("\t;;#ASMSTART", "\ts_nop 1\n\t;;#ASMSTART")
     assert build.audit_sgpr_hazards(far) == []
+
+
+def test_build_audit_flags_an_mfma_result_touched_early():
+    """The opposite hazard (round-3 advisory): the RESULT of an asm MFMA read by a VALU / LDS / VMEM instruction, or by
+    another MFMA as A / B, before the matrix pipe has written it back (8 passes: 11 wait states).  hipcc pads nothing
+    around an MFMA it cannot see, inside or outside the asm statements."""
+    build = _load(os.path.join(ROOT, "conceptattention_amd", "csrc", "build.py"), "ca_build")
+    mfma = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 v[34:49], a[192:195], a[128:131], v[2:17]\n\t;;#ASMEND\n"
+    # a compiler-placed copy right behind the statement (what commit 863ff6e's fault looked like from the other side)
+    early = mfma + "\tv_mov_b32_e32 v200, v40\n"
+    assert any("v_mov_b32_e32 v200, v40" in b for b in build.audit_mfma_result_hazards(early))
+    # the same copy two MFMA slots later is what the generated stream relies on: clean
+    other = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 v[50:65], a[192:195], a[160:163], v[18:33]\n\t;;#ASMEND\n"
+    other2 = other.replace("v[18:33]", "v[50:65]")     # the next MFMA of that chain (accumulates: interlocked)
+    assert build.audit_mfma_result_hazards(mfma + other + other2 + "\tv_mov_b32_e32 v200, v40\n") == []
+    # ... and one slot later is not (8 passes of the next MFMA + 1 < 11 + 1)
+    assert build.audit_mfma_result_hazards(mfma + other + "\tv_exp_f32 v40, v40\n") != []
+    # enough s_nop in between: clean; one state short: flagged
+    assert build.audit_mfma_result_hazards(mfma + "\ts_nop 10\n\tv_mov_b32_e32 v200, v40\n") == []
+    assert build.audit_mfma_result_hazards(mfma + "\ts_nop 9\n\tv_mov_b32_e32 v200, v40\n") != []
+    # an LDS write, a store and an MFMA taking the result as B are readers too; accumulating onto it is interlocked
+    assert build.audit_mfma_result_hazards(mfma + "\tds_write_b32 v1, v35\n") != []
+    assert build.audit_mfma_result_hazards(mfma + "\tglobal_store_dword v[0:1], v49, off\n") != []
+    asb = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 a[0:15], a[224:227], v[34:37], a[0:15]\n\t;;#ASMEND\n"
+    assert build.audit_mfma_result_hazards(mfma + asb) != []
+    acc = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 v[34:49], a[196:199], a[132:135], v[34:49]\n\t;;#ASMEND\n"
+    assert build.audit_mfma_result_hazards(mfma + acc) == []
+    # the accumulator file: O^T read back too early (CA_A4_SCALE_O / READ_O start with 24 wait states for this)
+    pv = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 a[0:15], a[224:227], v[2:5], a[0:15]\n\t;;#ASMEND\n"
+    assert build.audit_mfma_result_hazards(pv + "\t;;#ASMSTART\n\tv_accvgpr_read_b32 v9, a3\n\t;;#ASMEND\n") != []
+    assert build.audit_mfma_result_hazards(pv + "\t;;#ASMSTART\n\ts_nop 15\n\tv_accvgpr_read_b32 v9, a3\n\t;;#ASMEND\n") == []
+
+
+def test_build_audit_carries_the_history_across_branches():
+    """The state at a branch travels to its target: the tile loop's R = 2 -> R = 0 back-edge, and a forward branch that
+    skips the padding which makes the fall-through path legal."""
+    build = _load(os.path.join(ROOT, "conceptattention_amd", "csrc", "build.py"), "ca_build")
+    mfma = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 v[34:49], a[192:195], a[128:131], v[2:17]\n\t;;#ASMEND\n"
+    loop = ".LBB0_1:\n\tv_add_f32_e32 v40, v40, v41\n\ts_nop 15\n" + mfma + "\ts_cbranch_scc1 .LBB0_1\n"
+    assert any("v_add_f32_e32 v40" in b for b in build.audit_mfma_result_hazards(loop))
+    fwd = mfma + "\ts_cbranch_vccnz .LBB0_9\n\ts_nop 15\n.LBB0_9:\n\tv_add_f32_e32 v40, v40, v41\n"
+    assert any("v_add_f32_e32 v40" in b for b in build.audit_mfma_result_hazards(fwd))
+    ok = ".LBB0_1:\n\ts_nop 15\n\tv_add_f32_e32 v40, v40, v41\n" + mfma + "\ts_cbranch_scc1 .LBB0_1\n"
+    assert build.audit_mfma_result_hazards(ok) == []
+
+
+def test_build_audit_allows_only_scalar_code_inside_the_generated_stream():
+    build = _load(os.path.join(ROOT, "conceptattention_amd", "csrc", "build.py"), "ca_build")
+    a = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 v[34:49], a[192:195], a[128:131], v[2:17] ; a4s\n\t;;#ASMEND\n"
+    b = "\t;;#ASMSTART\n\tv_exp_f32 v66, v66 ; a4s\n\tv_add_f32 v143, v143, v96\n\t;;#ASMEND\n"
+    a2 = a.replace("v[2:17]", "v[34:49]")              # the chain's next MFMA
+    assert build.audit_mfma_result_hazards(a + "\ts_nop 0\n" + b + "\ts_add_i32 s0, s18, 0x400\n" + a2) == []
+    moved = a + "\tv_mov_b32_e32 v201, v96\n" + b
+    assert any("inside the generated stream" in x for x in build.audit_mfma_result_hazards(moved))
+    # the same instruction between the stream and an unmarked helper statement is hipcc's business
+    helper = "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\t;;#ASMEND\n"
+    assert build.audit_mfma_result_hazards(b + helper + "\tv_mov_b32_e32 v201, v96\n" + b) == []
+
+
+def test_shipped_stream_is_marked_for_the_audit():
+    text = open(INC).read()
+    sched = text[text.index("#ifdef CA_A4_SCHEDULE"):]
+    assert sched.count("; a4s") == 3 * 128   # two statements per MFMA slot, three iteration variants

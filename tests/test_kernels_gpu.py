@@ -480,6 +480,132 @@ def test_attention_full_size(prescaled):
     close(out, ref, atol=5e-3)
 
 
+def _peaky_case(kind, nq, nk, seed=0):
+    """q (unscaled), k, v with a chosen logit distribution (nats): 'std<s>' = i.i.d. logits of that spread;
+    'structured' = every row sees its first 64 keys near -20 nats and a few late keys near +25 (the text tile is cold,
+    a handful of image keys carry the row: what a trained head can look like)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if kind.startswith("std"):
+        s = float(kind[3:])
+        a = math.sqrt(s)                     # logit = q.k / sqrt(128), q, k ~ a N(0,1): std = a^2
+        q = torch.randn(nq, 128, generator=g) * a
+        k = torch.randn(nk, 128, generator=g) * a
+    else:
+        u = torch.randn(128, generator=g)
+        u = u / u.norm()
+        q = u[None, :] * (math.sqrt(128.0) ** 0.5 * 3.0) + torch.randn(nq, 128, generator=g) * 0.05
+        k = torch.randn(nk, 128, generator=g) * 0.05
+        qs = float((q[0] @ u))
+        k[:64] += u[None, :] * (-20.0 * math.sqrt(128.0) / qs)
+        hot = torch.randperm(nk - 64, generator=g)[:5] + 64
+        k[hot] += u[None, :] * (25.0 * math.sqrt(128.0) / qs)
+    v = torch.randn(nk, 128, generator=g)
+    return q.to(DEV).bfloat16(), k.to(DEV).bfloat16(), v.to(DEV).bfloat16()
+
+
+@pytest.mark.parametrize("kind", ["std1", "std4", "std8", "std16", "structured"])
+def test_attention_peaky_distributions_rereference_in_place(kind):
+    """ca_attn4_kernel keeps tile 0's maximum as the softmax reference; on peaky logits a wave whose running row sums
+    pass 2^20 moves its rows' references up IN PLACE (exact powers of two, no key visited twice).  Accuracy against the
+    fp32 reference on each distribution, and the counters say which path ran: no workgroup may need the classical
+    recomputation on any of these (round 3's kernel recomputed every workgroup of the structured case)."""
+    nh, nq, nk = 1, 300, 4352 - 13            # ragged last tile; the second workgroup has an inactive wave (300 - 256 <= 64)
+    q0, k, v = _peaky_case(kind, nq, nk)
+    q, qe, kw = attn_forms(q0, True)
+    out = torch.zeros(nq, 128, device=DEV, dtype=torch.bfloat16)
+    ops.attention_stats(reset=True)
+    ops.attention([ops.Attn(q, out, k, v)], nh, **kw)
+    torch.cuda.synchronize()
+    st = ops.attention_stats()
+    ref = attn_ref(qe, k, v, nh)
+    close(out, ref, atol=1e-2)
+    assert st["recomputed_workgroups"] == 0, st
+    if kind in ("std1", "std4"):
+        assert st["rereference_events"] == 0, st          # the model's own statistics never leave the fast path
+    if kind in ("std16", "structured"):
+        assert st["rereference_events"] > 0, st
+
+
+@pytest.mark.parametrize("octaves", [58.0, 62.0, 95.0, 110.0, 130.0])
+def test_attention_late_spike_around_the_old_and_new_limits(octaves):
+    """A single late key `octaves` above its row's tile-0 reference, in a launch with a ragged tail and an inactive wave
+    (nq % 256 <= 192): below / above round 3's 2^60 limit (58, 62: now the in-place re-reference), below the point
+    where fp32 overflows between two checks (95), and beyond it (110, 130: exp2 overflows to inf, the final check
+    sends the workgroup through the classical recomputation).  All against the fp32 reference."""
+    nh, nq, nk = 1, 256 + 130, 64 * 11 + 5
+    q0, k, v = rnd(nq, 128), rnd(nk, 128, seed=3) * 0.05, rnd(nk, 128, seed=4)
+    row = 256 + 70                             # second workgroup, its second wave; waves 3 of it have no rows
+    qn = float(q0[row].float().pow(2).sum())
+    alpha = octaves / 1.4426950408889634 * math.sqrt(128.0) / qn
+    k[64 * 6 + 9] = (q0[row].float() * alpha).bfloat16()
+    q, qe, kw = attn_forms(q0, True)
+    out = torch.zeros(nq, 128, device=DEV, dtype=torch.bfloat16)
+    ops.attention_stats(reset=True)
+    ops.attention([ops.Attn(q, out, k, v)], nh, **kw)
+    torch.cuda.synchronize()
+    st = ops.attention_stats()
+    close(out, attn_ref(qe, k, v, nh), atol=1e-2)
+    assert (out[row].float() - v[64 * 6 + 9].float()).abs().max() < 5e-2     # one-hot on the spike's value row
+    if octaves <= 95.0:
+        assert st["recomputed_workgroups"] == 0 and st["rereference_events"] >= 1, st
+    if octaves >= 130.0:
+        assert st["recomputed_workgroups"] == 1, st
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_attention_nan_and_inf_keys_propagate_and_nothing_hangs(bad):
+    """A NaN / inf element in K: the rows that see it come out NaN (as torch's SDPA gives), every other workgroup's
+    rows are untouched, and the launch ends (every wave reaches the same barriers on the recomputation path, waves
+    without query rows included)."""
+    nh, nq, nk = 2, 256 + 70, 64 * 9 + 17
+    H = nh * 128
+    q0, k, v = rnd(nq, H), rnd(nk, H, seed=3), rnd(nk, H, seed=4)
+    k[300, 5] = bad                           # head 0 only
+    q, qe, kw = attn_forms(q0, True)
+    out = torch.zeros(nq, H, device=DEV, dtype=torch.bfloat16)
+    ops.attention([ops.Attn(q, out, k, v)], nh, **kw)
+    torch.cuda.synchronize()
+    ref = attn_ref(qe, k, v, nh)
+    bad_rows = torch.isnan(ref[:, :128]).any(1)           # NaN: every row; inf: the rows whose q[5] makes the score +inf
+    assert bad_rows.any()
+    assert torch.equal(torch.isnan(out[:, :128].float()).any(1), bad_rows)
+    assert torch.isnan(out[bad_rows][:, :128].float()).all()
+    if (~bad_rows).any():
+        close(out[~bad_rows][:, :128], ref[~bad_rows][:, :128], atol=1e-2)
+    close(out[:, 128:], ref[:, 128:], atol=1e-2)          # head 1 never saw it
+
+
+def test_attention_kv_base_with_bit_31_set():
+    """Regression for commit 1e7c133: `readfirstlane` returns int, and a 64-bit tile base built as (hi << 32) | lo
+    sign-extended a low half with bit 31 set -- a fault that came and went with the allocation addresses.  Place K / V
+    (and q / out) at an address whose bit 31 is set, deterministically: somewhere inside a 2.5 GiB allocation."""
+    nh, nq, nk = 2, 300, 64 * 7 + 3
+    H = nh * 128
+    big = torch.empty(5 * (1 << 29), dtype=torch.uint8, device=DEV)          # 2.5 GiB spans a bit-31 region
+    base = big.data_ptr()
+    start = base if base & 0x80000000 else ((base >> 31) + 1) << 31          # first address with bit 31 set
+    start = (start + 255) & ~255
+    need = (nq + 2 * nk) * H * 2 + nq * H * 2
+    assert start + need + 4096 <= base + big.numel() and (start & 0x80000000)
+    off = start - base
+    def view(n_rows, o):
+        return big[o:o + n_rows * H * 2].view(torch.bfloat16).view(n_rows, H)
+    qv, kv, vv, ov = view(nq, off), view(nk, off + nq * H * 2), view(nk, off + (nq + nk) * H * 2), \
+        view(nq, off + (nq + 2 * nk) * H * 2)
+    assert all(t.data_ptr() & 0x80000000 for t in (qv, kv, vv, ov))
+    q0, k, v = rnd(nq, H), rnd(nk, H, seed=3), rnd(nk, H, seed=4)
+    q, qe, kw = attn_forms(q0, True)
+    qv.copy_(q), kv.copy_(k), vv.copy_(v), ov.zero_()
+    ops.attention([ops.Attn(qv, ov, kv, vv)], nh, **kw)
+    torch.cuda.synchronize()
+    close(ov, attn_ref(qe, k, v, nh), atol=1e-2)
+    # the same through two key segments (the descriptor of segment 1 is "the address key 0 WOULD have": below the buffer)
+    ov.zero_()
+    ops.attention([ops.Attn(qv, ov, kv[:100], vv[:100], kv[100:], vv[100:])], nh, **kw)
+    torch.cuda.synchronize()
+    close(ov, attn_ref(qe, k, v, nh), atol=1e-2)
+
+
 def test_attention_shape_fuzz():
     """tools/fuzz_attn4.py: 80 random launches of the pre-scaled kernel (1-3 problems, 1-3 heads, query / key row counts
     around the tile and workgroup boundaries, one or two key segments that are not adjacent in memory, one or two query

@@ -114,6 +114,18 @@ def main():
                 Rnd("fp32_residual+fp32_qpre_con", resid=False, qpre_con=False),
                 Rnd("fp32_residual+fp32_qpre", resid=False, qpre_con=False, qpre_img=False),
                 Rnd("fp32_residual+fp32_qpre+split_xm_q", resid=False, qpre_con=False, qpre_img=False, xm_q=False)]
+    # round 4: the OUTPUT space, starting from what the HIP path stores today (fp32 residual, fp32 attention rows in the
+    # captured layers -- emulated for every layer here --, fp32 cross-space vectors); one rounding lifted at a time
+    now = dict(resid=False, attn=False, qpre_con=False, qpre_img=False, xm_q=False)
+    out_space = [Rnd("r4_today", **now),
+                 Rnd("r4_today+fp32_p", **now, p=False),
+                 Rnd("r4_today+fp32_qkv", **now, qkv=False),
+                 Rnd("r4_today+fp32_xm", **dict(now, xm=False)),
+                 Rnd("r4_today+fp32_xm+fp32_qkv", **dict(now, xm=False), qkv=False),
+                 Rnd("r4_today+fp32_hid", **now, hid=False),
+                 Rnd("r4_today+fp32_xm+fp32_qkv+fp32_p", **dict(now, xm=False), qkv=False, p=False)]
+    if len(sys.argv) > 1 and sys.argv[1] == "--out-space":
+        variants, sys.argv = out_space, sys.argv[:1] + sys.argv[2:]
     if len(sys.argv) > 1:
         variants = [v for v in variants if v.name.split("(")[0] in sys.argv[1:]]
     nh = p.num_heads
@@ -149,7 +161,8 @@ def main():
            "layers_15_18_cross": {k: max(v["cross"][15:19]) for k, v in res.items()},
            "mean_map_layers_15_18_cross": {k: float(np.abs(v).max()) for k, v in mean_cross.items()}}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "error_budget.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", os.environ.get("CA_BUDGET_OUT", "error_budget.json")), "w"),
+              indent=1)
     print(json.dumps(out["layers_15_18_out"], indent=1))
     print(json.dumps(out["layers_15_18_cross"], indent=1))
     print(json.dumps(out["mean_map_layers_15_18_cross"], indent=1))

@@ -1,0 +1,116 @@
+"""What the kept softmax reference of ca_attn4_kernel costs on peaky logits.
+
+The kernel takes tile 0's row maximum as the softmax reference and keeps it; every parity number and the bench live on
+the synthetic weights' near-uniform attention (logit std ~ 1 nat).  This tool times the 5-item attention launch of the
+path (5 x [256 text + 4096 image rows], 24 heads, q pre-scaled) on logits of std 1 / 4 / 8 / 16 nats and on a structured
+case (every row: its first 64 keys -- the text tile -- near -20 nats, five image keys near +25, the rest near 0), reads
+the kernel's rare-path counters (ca_attn_stats: recomputed workgroups, in-place re-reference events) and checks the
+result against an fp32 softmax on a sample of rows.  Run once per mode in fresh processes: the default kernel and
+CA_ATTN_REREF=0 (round 3's behaviour: no in-place re-reference, a row sum that leaves the safe range costs its
+workgroup a full classical recomputation).
+
+    python tools/attn_peaky.py [out.json]        (GPU box; default gpurun_out/attn_peaky.json)
+"""
+import json
+import math
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+B, T, Li, NH = 5, 256, 4096, 24
+H = NH * 128
+SL2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+KINDS = ["std1", "std4", "std8", "std16", "structured"]
+
+
+def make(kind, dev):
+    import torch
+    g = torch.Generator(device=dev).manual_seed(7)
+    n = B * (T + Li)
+    if kind.startswith("std"):
+        a = math.sqrt(float(kind[3:]))
+        q = torch.randn(n, NH, 128, device=dev, generator=g) * a
+        k = torch.randn(n, NH, 128, device=dev, generator=g) * a
+    else:
+        u = torch.randn(NH, 128, device=dev, generator=g)
+        u = u / u.norm(dim=1, keepdim=True)
+        qs = math.sqrt(math.sqrt(128.0)) * 3.0
+        q = u[None] * qs + torch.randn(n, NH, 128, device=dev, generator=g) * 0.05
+        k = torch.randn(n, NH, 128, device=dev, generator=g) * 0.05
+        for j in range(B):
+            t0 = j * T                                   # item j's text rows come first in its key order
+            k[t0:t0 + 64] += u[None] * (-20.0 * math.sqrt(128.0) / qs)
+            hot = B * T + j * Li + torch.randperm(Li, device=dev, generator=g)[:5]
+            k[hot] += u[None] * (25.0 * math.sqrt(128.0) / qs)
+    v = torch.randn(n, NH, 128, device=dev, generator=g)
+    return q.reshape(n, H), k.reshape(n, H).bfloat16(), v.reshape(n, H).bfloat16()
+
+
+def run_mode(out_path):
+    import torch
+    from conceptattention_amd import ops
+    from tools.bench_kernels import timeit
+    dev = "cuda"
+    res = {}
+    for kind in KINDS:
+        q0, k, v = make(kind, dev)
+        qp = (q0 * SL2).bfloat16()
+        out = torch.zeros(B * (T + Li), H, device=dev, dtype=torch.bfloat16)
+        probs = []
+        for j in range(B):
+            tj, ij = slice(j * T, (j + 1) * T), slice(B * T + j * Li, B * T + (j + 1) * Li)
+            probs.append(ops.Attn(qp[tj], out[tj], k[tj], v[tj], k[ij], v[ij], q1=qp[ij], out1=out[ij]))
+        ops.attention_stats(reset=True)
+        ops.attention(probs, NH, q_prescaled=True)
+        torch.cuda.synchronize()
+        st = ops.attention_stats()
+        t = min(timeit(lambda: ops.attention(probs, NH, q_prescaled=True), iters=10, warm=2) for _ in range(3))
+        # accuracy on a sample: item 0, heads 0 and 13, 320 query rows spread over text and image
+        rows = torch.cat((torch.arange(0, 64), torch.arange(B * T, B * T + 256))).to(dev)
+        keys = torch.cat((torch.arange(0, T), torch.arange(B * T, B * T + Li))).to(dev)
+        err = 0.0
+        for h in (0, 13):
+            c = slice(h * 128, (h + 1) * 128)
+            qe = qp[rows][:, c].float() / SL2
+            s = qe @ k[keys][:, c].float().t() / math.sqrt(128.0)
+            ref = torch.softmax(s, dim=-1) @ v[keys][:, c].float()
+            err = max(err, float((out[rows][:, c].float() - ref).abs().max()))
+            lg = s
+        wgs = 8 * 3 * 17 * B
+        res[kind] = {"us_per_launch": t * 1e6, "tflops": B * 4.0 * (T + Li) ** 2 * 128 * NH / t / 1e12,
+                     "recomputed_workgroups": st["recomputed_workgroups"], "workgroups": wgs,
+                     "recompute_rate": st["recomputed_workgroups"] / wgs,
+                     "rereference_events_per_launch": st["rereference_events"], "waves": wgs * 4,
+                     "max_abs_err_vs_fp32_sample": err,
+                     "sample_logit_std_nats": float(lg.std()), "sample_logit_max_minus_tile0_max_nats":
+                         float((lg.max(1).values - lg[:, :64].max(1).values).max())}
+        print(kind, json.dumps(res[kind]), flush=True)
+    json.dump(res, open(out_path, "w"))
+
+
+def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--mode":
+        return run_mode(sys.argv[2])
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "attn_peaky.json")
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    doc = {"shape": f"{B} problems x ({T} + {Li}) rows, {NH} heads, head_dim 128, q pre-scaled (ca_attn4_kernel)",
+           "method": "best of 3 x 10 launches after 2 warm-ups (HIP events); counters of ONE launch (ca_attn_stats); error on "
+                     "320 query rows x 2 heads of item 0 against an fp32 softmax of the same bf16 inputs"}
+    for mode, env in (("rereference(default)", {}), ("no_rereference(CA_ATTN_REREF=0, round-3 behaviour)",
+                                                      {"CA_ATTN_REREF": "0"})):
+        tmp = out + "." + mode.split("(")[0] + ".tmp"
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", tmp], check=True, env=dict(os.environ, **env))
+        doc[mode] = json.load(open(tmp))
+        os.remove(tmp)
+    base = doc["rereference(default)"]["std1"]["us_per_launch"]
+    doc["slowdown_vs_std1"] = {m: {k: doc[m][k]["us_per_launch"] / base for k in KINDS}
+                               for m in doc if isinstance(doc[m], dict) and "std1" in doc[m]}
+    json.dump(doc, open(out, "w"), indent=1)
+    print("written", out)
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,9 @@ class Stream:
         text = []
         for tpl, ops in self.cur:
             text.append(tpl.format(*[f"%{num[e]}" for e, _ in ops]))
+        # marker of a stream statement (a comment in the emitted assembly): build.py's audit fails the build on any
+        # vector / memory instruction hipcc places BETWEEN two marked statements of one basic block
+        text[0] += " ; a4s"
         cls = lambda e: "s" if "s" in mode[e] else "v"     # mode letter 's': a scalar (SGPR) operand
         o = ", ".join(f'"{"+" if "r" in mode[e] else "=&"}{cls(e)}"({e})' for e in outs)
         i = ", ".join(f'"{cls(e)}"({e})' for e in inps)
