@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CA_LIB_PATH: another build of the same library (A/B and diagnostic builds under tools/ab_libs); still no fallback
 LIB_PATH = os.environ.get("CA_LIB_PATH") or os.path.join(_HERE, "libconceptattn.so")
 
-CA_VERSION = 122
+CA_VERSION = 123
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU, EPI_QKV_NORM_ROPE = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_256x256, TILE_256x192, TILE_256x128, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_PP_256x256, TILE_PP_256x128, TILE_PP_256x192 = 5, 6, 7
@@ -34,7 +34,7 @@ class GemmProblem(C.Structure):
                 ("ld2", C.c_int32), ("n_split", C.c_int32), ("gate_rows", C.c_int32),
                 ("epilogue", C.c_int32), ("ldp", C.c_int32), ("out_f32", C.c_int32), ("gate_stride", C.c_int32),
                 ("gate_item_rows", C.c_int32), ("gate2_item_rows", C.c_int32),
-                ("qpre_f32", C.c_int32), ("q_out_scale", C.c_float)]
+                ("qpre_f32", C.c_int32), ("q_out_scale", C.c_float), ("qk_f16", C.c_int32), ("_pad", C.c_int32)]
 
 
 class AttnProblem(C.Structure):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "ca_gemm_auto_tile": (C.c_int, [C.POINTER(GemmProblem), C.c_int32]),
     "ca_gemm_fp8": (C.c_int, [C.POINTER(GemmProblem), C.c_int32, C.c_void_p]),
     "ca_attn_fwd_bf16": (C.c_int, [C.POINTER(AttnProblem), C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "ca_attn_fwd_qk16": (C.c_int, [C.POINTER(AttnProblem), C.c_int32, C.c_int32, C.c_void_p]),
     "ca_attn_stats": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int32]),
     "ca_ln_modulate_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),

@@ -12,7 +12,7 @@ SOURCES = ["ca_api.hip", "ca_gemm.hip", "ca_attn.hip", "ca_attn4.hip", "ca_rowop
 # ca_attn4.hip owns the AGPR file by hand (literal a[...] registers in its asm statements): hipcc must never park a
 # VGPR there (its default spill target), and the emitted code is audited for it below
 EXTRA_FLAGS = {"ca_attn4.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj"]}
-HEADERS = ["ca_common.h", "ca_attn_common.h", "ca_attn4_sched.inc"]
+HEADERS = ["ca_common.h", "ca_attn_common.h", "ca_attn4_sched.inc", "ca_attn4_kernel.inc"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 
@@ -43,11 +43,12 @@ def audit_attn4(asm_path: str) -> None:
             bad.append(line.strip())
     bad += audit_sgpr_hazards(text)
     bad += audit_mfma_result_hazards(text)
-    m = re.search(r"\.vgpr_spill_count:\s*(\d+)", text)
-    scratch = re.search(r"\.private_segment_fixed_size:\s*(\d+)", text)
-    if bad or (m and int(m.group(1))) or (scratch and int(scratch.group(1))):
-        raise RuntimeError(f"ca_attn4.hip audit failed: compiler AGPR / M0 accesses {bad[:5]}, vgpr spills "
-                           f"{m.group(1) if m else '?'}, scratch {scratch.group(1) if scratch else '?'} bytes")
+    # (every kernel of the unit: the bf16 and the half-precision-q/k instantiation)
+    spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s*(\d+)", text)]
+    scratch = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text)]
+    if bad or any(spills) or any(scratch) or not spills:
+        raise RuntimeError(f"ca_attn4.hip audit failed: compiler AGPR / M0 accesses / hazards {bad[:5]}, vgpr spills "
+                           f"{spills}, scratch {scratch} bytes")
     for tmp in os.listdir(HERE):   # -save-temps leftovers
         if tmp.startswith("ca_attn4-") and not tmp.endswith(".s"):
             os.remove(os.path.join(HERE, tmp))

@@ -369,8 +369,21 @@ __global__ __launch_bounds__(NW * 64, 2) void ca_attn_kernel(const AttnLaunch L)
 
 }  // namespace
 
+static int ca_attn_fwd_impl(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads, float scale,
+                            bool qk_f16, ca_stream_t stream);
+
 extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
                                 float scale, ca_stream_t stream) {
+  return ca_attn_fwd_impl(problems, n_problems, num_heads, scale, false, stream);
+}
+
+extern "C" int ca_attn_fwd_qk16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
+                                ca_stream_t stream) {
+  return ca_attn_fwd_impl(problems, n_problems, num_heads, CA_ATTN_Q_PRESCALED, true, stream);
+}
+
+static int ca_attn_fwd_impl(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads, float scale,
+                            bool qk_f16, ca_stream_t stream) {
   if (!problems || n_problems < 1 || n_problems > CA_ATTN_MAX_PROBLEMS || num_heads < 1 || !(scale >= 0.0f)) {
     ca_set_error("ca_attn_fwd_bf16: n_problems=%d (max %d) num_heads=%d scale=%g", n_problems, CA_ATTN_MAX_PROBLEMS,
                  num_heads, (double)scale);
@@ -384,14 +397,15 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
   // as well, same numerics contract).  A/B aid: CA_ATTN_KERNEL=8 sends pre-scaled q through the two-waves-per-SIMD
   // kernel below, which also serves every call that passes a scale.
   static const bool want4 = !(getenv("CA_ATTN_KERNEL") && atoi(getenv("CA_ATTN_KERNEL")) == 8);
-  const bool use4 = pre && want4;
+  const bool use4 = (pre && want4) || qk_f16;   // (half-precision q / k exist in the one-wave-per-SIMD kernel only)
   const int qrows = use4 ? 256 : nw * 32;
   AttnLaunch L = {};
   L.num_heads = num_heads;
   L.n_problems = n_problems;
   L.scale_log2 = scale * 1.4426950408889634f;
   static const bool no_reref = getenv("CA_ATTN_REREF") && atoi(getenv("CA_ATTN_REREF")) == 0;
-  L.flags = no_reref ? 1 : 0;
+  static const bool limit60 = getenv("CA_ATTN_LIMIT60") && atoi(getenv("CA_ATTN_LIMIT60")) == 1;
+  L.flags = (no_reref ? 1 : 0) | (limit60 ? 2 : 0);
   const int hx = (num_heads + 7) / 8;  // heads per XCD group
   int total = 0;
   for (int i = 0; i < n_problems; ++i) {
@@ -433,7 +447,7 @@ extern "C" int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_probl
     L.blk_end[i] = total;
   }
   if (use4) {
-    const int rc = ca_attn4_launch(L, total, (hipStream_t)stream);
+    const int rc = ca_attn4_launch(L, total, qk_f16, (hipStream_t)stream);
     if (rc != CA_OK) return rc;
     const hipError_t e4 = hipGetLastError();
     if (e4 != hipSuccess) {

@@ -10,7 +10,8 @@ struct AttnLaunch {
   int32_t n_problems;
   int32_t num_heads;
   float scale_log2;   // softmax scale * log2(e)
-  int32_t flags;      // bit 0: ca_attn4_kernel without its in-place re-reference (CA_ATTN_REREF=0, an A/B aid)
+  int32_t flags;      // bit 0: ca_attn4_kernel without its in-place re-reference (CA_ATTN_REREF=0), bit 1: with round 3's
+                      // row-sum limit of 2^60 instead of 2^100 (CA_ATTN_LIMIT60=1); both A/B aids of tools/attn_peaky.py
 };
 
 constexpr int KV_TILE = 64;
@@ -22,6 +23,6 @@ constexpr int ATTN_LDS = 2 * BUF_BYTES;
 }  // namespace ca_attn_detail
 
 // ca_attn4.hip: the one-wave-per-SIMD kernel for pre-scaled q (host side: attribute once per device, launch)
-int ca_attn4_launch(const ca_attn_detail::AttnLaunch &L, int total_workgroups, hipStream_t stream);
+int ca_attn4_launch(const ca_attn_detail::AttnLaunch &L, int total_workgroups, bool qk_f16, hipStream_t stream);
 // counters of its two rare paths: out[0] = recomputed workgroups, out[1] = re-reference events (synchronous copy)
 int ca_attn4_read_counters(unsigned long long *out, int reset);

@@ -73,6 +73,13 @@ __device__ __forceinline__ uint32_t ca_pack2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// pack two floats into one dword of 2 x IEEE half (RNE; hipcc emits v_cvt_pk_f16_f32 on gfx950)
+__device__ __forceinline__ uint32_t ca_pack2_f16(float lo, float hi) {
+  typedef _Float16 ca_h2 __attribute__((ext_vector_type(2)));
+  ca_h2 v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
 __device__ __forceinline__ float ca_gelu_tanh(float x) {
   // nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  With
   // 0.5 (1 + tanh(u)) = sigmoid(2u) this is x / (1 + exp(-2u)); exp(-2u) = exp2(x (k0 + k1 x^2)),

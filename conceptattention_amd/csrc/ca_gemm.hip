@@ -793,8 +793,11 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
 #pragma unroll
             for (int i = 0; i < 8; ++i) z[i] = z[i] * qos;
           }
+          // (qk_f16: the rotated q / k as IEEE half for ca_attn_fwd_qk16 -- a launch-uniform branch)
           *(uint4 *)(outb + ((size_t)m * ldo + n0 + hn * 128 + cih) * 2) =
-              make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
+              P.qk_f16 ? make_uint4(ca_pack2_f16(z[0], z[1]), ca_pack2_f16(z[2], z[3]), ca_pack2_f16(z[4], z[5]),
+                                    ca_pack2_f16(z[6], z[7]))
+                       : make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
         }
       }
       return;
@@ -1175,7 +1178,9 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
         for (int i = 0; i < 8; ++i) z[i] = z[i] * qos;
       }
       *(uint4 *)(outb + ((size_t)m * ldo + n0 + cih) * 2) =
-          make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
+          P.qk_f16 ? make_uint4(ca_pack2_f16(z[0], z[1]), ca_pack2_f16(z[2], z[3]), ca_pack2_f16(z[4], z[5]),
+                                ca_pack2_f16(z[6], z[7]))
+                   : make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
     }
     return;
   }
@@ -1457,6 +1462,7 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
         if (tile != CA_TILE_PP_256x256 || p.n_split <= 0 || p.n_split % 768 || p.n_split > p.N || !p.norm_q ||
             !p.norm_k || !p.rope || (p.n_split < p.N && (!p.out2 || p.ld2 % 8 || p.ld2 < p.N - p.n_split)) ||
             p.ldc < p.n_split || (p.q_prerope && (p.ldp % (p.qpre_f32 ? 4 : 8) || p.ldp < p.n_split / 3 || p.qpre_f32 < 0 || p.qpre_f32 > 2)) ||
+            (p.qk_f16 != 0 && p.qk_f16 != 1) ||
             (((uintptr_t)p.norm_q | (uintptr_t)p.norm_k | (uintptr_t)p.rope | (uintptr_t)p.q_prerope |
               (uintptr_t)p.out2) & 15)) {
           ca_set_error("%s[%d]: QKV_NORM_ROPE needs the 256x256 ping-pong tile, n_split = 3*heads*128 <= N, "

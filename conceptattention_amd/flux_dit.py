@@ -218,6 +218,18 @@ class HipFluxDiT:
         # layers only: +0.45 % FLOPs per call), and ops.qpre_finish normalises the sum.  The q the ATTENTION uses is
         # untouched, so the image does not depend on which layers are captured.  "0" = one rounding more (A/B aid).
         self.split_q_capture = os.environ.get("CA_SPLIT_Q_CAPTURE", "1") != "0"
+        # The rotated q and k of the attention as IEEE half instead of bf16 (ca_gemm_problem.qk_f16 ->
+        # ca_attn_fwd_qk16): their bf16 rounding is what bounds a single output-space heat map (round 4,
+        # tests/tools/error_budget.py --out-space2: 9e-4 -> 2.5e-4 per map with 11-bit q / k; v and the probabilities
+        # do not matter), the f16 MFMA has the bf16 one's rate, and behind an RMS norm the values sit far inside
+        # fp16's range.  "all" (default): every block, so that the image does not depend on which layers are
+        # captured; "captured": only the layers whose maps are requested; "0": bf16 as the reference (A/B aid).
+        # Needs the pre-scaled-q kernel (CA_ATTN_PRESCALE / CA_ATTN_KERNEL=8 switch it off).
+        self.qk_f16 = os.environ.get("CA_QK_F16", "all")
+        if self.qk_f16 not in ("all", "captured", "0"):
+            raise ValueError("CA_QK_F16 must be all, captured or 0")
+        if not self.prescale_q or os.environ.get("CA_ATTN_KERNEL") == "8":
+            self.qk_f16 = "0"
         self.set_precision(precision)
 
     # ---- reduced-precision mode (BASELINE.json configs[4]; no counterpart in the reference)
@@ -582,6 +594,9 @@ class HipFluxDiT:
             g = self._ones_gate_vec = torch.ones(n, device=self.device, dtype=torch.float32)
         return g
 
+    def _qk16(self, capture: bool) -> bool:
+        return self.qk_f16 == "all" or (self.qk_f16 == "captured" and bool(capture))
+
     def _q_out_scale(self) -> float:
         """What the qkv epilogue multiplies the rotated q by: softmax_scale * log2(e) (head_dim 128), or 0 (= 1)."""
         return (1.0 / math.sqrt(128.0)) * 1.4426950408889634 if self.prescale_q else 0.0
@@ -628,6 +643,7 @@ class HipFluxDiT:
         # K5+K6+K7: qkv projections (image stream + [concept|text] stream in one grouped launch) with
         # QK-RMSNorm and RoPE fused into the epilogue; pre-RoPE q kept for the cross-attention maps
         qpre = self.QPRE if capture else None
+        qk16 = self._qk16(capture)
         if split:   # q weights applied to the low plane: image rows and the concept rows (text rows are not captured)
             # (256 x 256 tiles named: the automatic choice prices the concept rows' problem and lands on 256 x 128,
             # 376 vs 332 us per 5-item launch)
@@ -639,13 +655,13 @@ class HipFluxDiT:
                              L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
                              norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[oI:],
                              q_prerope=None if qpre is None else qpre[oI:], q_out_scale=self._q_out_scale(),
-                             qpre_raw=split),
+                             qpre_raw=split, qk_f16=qk16),
                            G(fp8, XM[:oI], rows(XM8, 0, oI), rows(XMS, 0, oI), b + "txt_attn.qkv.weight",
                              W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:oI],
                              L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
                              norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:oI],
                              q_prerope=None if qpre is None else qpre[:oI], q_out_scale=self._q_out_scale(),
-                             qpre_raw=split)])
+                             qpre_raw=split, qk_f16=qk16)])
         if split:
             ops.qpre_finish(qpre[oI:], self.QD[oI:], W[b + "img_attn.norm.query_norm.scale"], NH)
             ops.qpre_finish(qpre[:oT], self.QD[:oT], W[b + "txt_attn.norm.query_norm.scale"], NH)
@@ -667,7 +683,7 @@ class HipFluxDiT:
             tj, ij = slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)
             probs.append(ops.Attn(qs[tj], ATT[tj], ks[tj], vs[tj], ks[ij], vs[ij], q1=qs[ij], out1=ATT[ij],
                                   out_f32=self.ATTI32[j] if self._f32_image_vectors(capture, heatmaps) else None))
-        ops.attention(probs, NH, q_prescaled=self.prescale_q)
+        ops.attention(probs, NH, q_prescaled=self.prescale_q, qk_f16=qk16)
         if capture:
             self._capture(out, i, g, NH, return_vectors, heatmaps)
         if fp8:
@@ -721,13 +737,13 @@ class HipFluxDiT:
         self._launch_gemm([G(fp8, xms, xm8, xms8, b + "linear1.weight", W[b + "linear1.bias"], qkvs,
                              L.EPI_QKV_NORM_ROPE, out2=CAT[:, H:], n_split=3 * H, norm_q=W[b + "norm.query_norm.scale"],
                              norm_k=W[b + "norm.key_norm.scale"], rope=self.ROPE[oT:],
-                             q_out_scale=self._q_out_scale())])
+                             q_out_scale=self._q_out_scale(), qk_f16=self._qk16(False))])
         qh, kh, vh, oh = qkvs[:, :H], qkvs[:, H:2 * H], qkvs[:, 2 * H:], CAT[:, :H]
         probs = []
         for j in range(B):
             tj, ij = slice(j * T, (j + 1) * T), slice(nT + j * Li, nT + (j + 1) * Li)
             probs.append(ops.Attn(qh[tj], oh[tj], kh[tj], vh[tj], kh[ij], vh[ij], q1=qh[ij], out1=oh[ij]))
-        ops.attention(probs, NH, q_prescaled=self.prescale_q)
+        ops.attention(probs, NH, q_prescaled=self.prescale_q, qk_f16=self._qk16(False))
         if fp8:
             ops.quantize_rows_fp8(CAT, self.CAT8, self.CATS)
         gate = self._mod(m, 0, 2)

@@ -53,6 +53,7 @@ class Gemm:
     q_prerope: Optional[torch.Tensor] = None   # bf16 or fp32 [M, heads*128]
     q_out_scale: float = 0.0                   # QKV_NORM_ROPE: rotated q times this before rounding (0 = 1)
     qpre_raw: bool = False                     # fp32 q_prerope receives the projection BEFORE its norm (qpre_finish)
+    qk_f16: bool = False                       # QKV_NORM_ROPE: rotated q / k stored as fp16 bits (attention(qk_f16=True))
     a_scale: Optional[torch.Tensor] = None  # fp8 mode: a, w are uint8 (e4m3 bytes) with fp32 row scales
     w_scale: Optional[torch.Tensor] = None  # ([M] and [N]); the launch then goes to ca_gemm_fp8
     # batched forward: rows < gate_rows are items of gate_item_rows rows, the others items of gate2_item_rows rows;
@@ -104,6 +105,7 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
                 raise ValueError(f"gemm[{i}]: rope must be contiguous [M,64,2]")
             p.rope, p.n_split = rope.data_ptr(), g.n_split
             p.q_out_scale = float(g.q_out_scale)
+            p.qk_f16 = int(bool(g.qk_f16))
             if g.q_prerope is not None:
                 if g.q_prerope.dtype not in (torch.bfloat16, torch.float32):
                     raise ValueError(f"gemm[{i}]: q_prerope must be bf16 or fp32")
@@ -170,8 +172,9 @@ class Attn:
 
 
 def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] = None,
-              q_prescaled: bool = False) -> None:
-    """``q_prescaled``: the q rows already carry softmax_scale * log2(e) (Gemm.q_out_scale; CA_ATTN_Q_PRESCALED)."""
+              q_prescaled: bool = False, qk_f16: bool = False) -> None:
+    """``q_prescaled``: the q rows already carry softmax_scale * log2(e) (Gemm.q_out_scale; CA_ATTN_Q_PRESCALED).
+    ``qk_f16`` (with q_prescaled): the q and k rows hold IEEE half bits in their bf16-typed tensors (Gemm.qk_f16)."""
     lib = L.load()
     arr = (L.AttnProblem * len(problems))()
     for i, a in enumerate(problems):
@@ -200,6 +203,8 @@ def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] =
             if a.out_f32.shape[0] != p.nq:
                 raise ValueError(f"attention[{i}]: out_f32 row mismatch")
             p.out_f32, p.ldo32 = a.out_f32.data_ptr(), a.out_f32.stride(0)
+    if qk_f16 and not q_prescaled:
+        raise ValueError("attention: qk_f16 needs q_prescaled (ca_attn_fwd_qk16)")
     if q_prescaled:
         if scale is not None:
             raise ValueError("attention: give either scale or q_prescaled")
@@ -208,11 +213,16 @@ def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] =
         scale = 1.0 / math.sqrt(128.0)
     elif not scale > 0:
         raise ValueError("attention: scale must be > 0")
+    if qk_f16:
+        def launch():
+            L.check(lib.ca_attn_fwd_qk16(arr, len(problems), num_heads, _stream()), "ca_attn_fwd_qk16")
+    else:
+        def launch():
+            L.check(lib.ca_attn_fwd_bf16(arr, len(problems), num_heads, scale, _stream()), "ca_attn_fwd_bf16")
     if _attn_hook is not None:
-        _attn_hook(arr, num_heads, lambda: L.check(lib.ca_attn_fwd_bf16(arr, len(problems), num_heads, scale,
-                                                                          _stream()), "ca_attn_fwd_bf16"))
+        _attn_hook(arr, num_heads, launch)
         return
-    L.check(lib.ca_attn_fwd_bf16(arr, len(problems), num_heads, scale, _stream()), "ca_attn_fwd_bf16")
+    launch()
 
 
 def attention_stats(reset: bool = False) -> dict:

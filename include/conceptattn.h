@@ -28,8 +28,9 @@
 extern "C" {
 #endif
 
-#define CA_VERSION 122 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
-                          CA_ATTN_Q_PRESCALED; .1: ca_axpy_f32, ca_split_bf16; .2: ca_attn_stats */
+#define CA_VERSION 123 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
+                          CA_ATTN_Q_PRESCALED; .1: ca_axpy_f32, ca_split_bf16; .2: ca_attn_stats; .3: ca_gemm_problem.qk_f16,
+                          ca_attn_fwd_qk16 */
 
 #define CA_OK 0
 #define CA_ERR_ARG (-1)    /* bad shape / null pointer / misalignment */
@@ -114,6 +115,10 @@ typedef struct {
   float q_out_scale;       /* QKV_NORM_ROPE: the rotated q is multiplied by this in fp32 before its ONE rounding   */
                            /* to bf16 (0 = 1.0; k, v and q_prerope are not scaled).  With softmax_scale * log2(e)  */
                            /* here, ca_attn_fwd_bf16(scale = CA_ATTN_Q_PRESCALED) needs no per-score multiply      */
+  int32_t qk_f16;          /* QKV_NORM_ROPE: 1 = the rotated q and k are stored as IEEE half (fp16, 11-bit         */
+                           /* mantissa; |values| stay far below 65504 behind an RMS norm) in the same 2-byte       */
+                           /* elements of `out`; v stays bf16.  Read by ca_attn_fwd_qk16.  0 = bf16                */
+  int32_t _pad;
 } ca_gemm_problem;
 
 int ca_gemm_bf16(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile, ca_stream_t stream);
@@ -168,10 +173,15 @@ typedef struct {
 #define CA_ATTN_Q_PRESCALED 0.0f
 int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads,
                      float scale, ca_stream_t stream);
+/* ca_attn_fwd_bf16(scale = CA_ATTN_Q_PRESCALED) for q and k rows that hold IEEE half (fp16) instead of bf16 -- written
+ * so by the qkv epilogue with ca_gemm_problem.qk_f16 = 1; v, the probabilities and the outputs stay bf16 / fp32.  Used
+ * for the layers whose heat maps are requested: the bf16 rounding of the rotated q and k is what bounds the output-
+ * space maps (modified_double_stream_block.py:185-191 on :112-116), and an 11-bit mantissa costs the MFMA nothing. */
+int ca_attn_fwd_qk16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads, ca_stream_t stream);
 /* Diagnostics of the pre-scaled-q kernel's two rare paths on the current device, since the last reset:
- * counters[0] = workgroups whose rows were recomputed with a running maximum (a row sum overflowed: a score more
- * than ~80 octaves above the running softmax reference, or inf / NaN inputs), counters[1] = in-place re-reference
- * events (per wave: a running row sum passed 2^20 and the reference was moved up).  Both are 0 on the data the
+ * counters[0] = workgroups whose rows were recomputed with a running maximum (a row sum passed 2^100 or
+ * overflowed: a score > 100 octaves above its row's first-tile maximum with no check in between, or inf / NaN inputs),
+ * counters[1] = in-place re-reference events (per wave: a running row sum passed 2^64 and the reference was moved up).  Both are 0 on the data the
  * reference's synthetic weights produce.  A blocking device-to-host copy: not for the hot path; reset != 0 zeroes them. */
 int ca_attn_stats(unsigned long long *counters, int32_t reset);
 

@@ -34,7 +34,7 @@ def test_version_and_error_string(lib):
 
 def test_struct_layouts_match_header():
     # sizes the C compiler sees (LP64): pointers 8, int32 4, no implicit padding inside
-    assert ctypes.sizeof(L.GemmProblem) == 14 * 8 + 18 * 4   # 16 int32 + qpre_f32 + float q_out_scale
+    assert ctypes.sizeof(L.GemmProblem) == 14 * 8 + 20 * 4   # 16 int32 + qpre_f32 + float q_out_scale + qk_f16 + pad
     assert ctypes.sizeof(L.AttnProblem) == 9 * 8 + 8 * 4 + 3 * 4 + 4  # trailing pad to 8-byte alignment
     assert ctypes.sizeof(L.ModSegment) == 24 and ctypes.sizeof(L.NormSegment) == 24
 

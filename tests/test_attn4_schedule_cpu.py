@@ -40,7 +40,8 @@ def test_stream_shape():
     variants = sched.split("---- iteration variant")[1:]
     assert len(variants) == 3
     for v in variants:
-        assert v.count("v_mfma_f32_32x32x16_bf16") == 64
+        assert v.count("v_mfma_f32_32x32x16_") == 64
+        assert v.count('v_mfma_f32_32x32x16_" CA_A4_QK_T "') == 32 and v.count("v_mfma_f32_32x32x16_bf16") == 32
         assert v.count("v_exp_f32") == 64 and v.count("v_add_f32") == 64 and v.count("v_cvt_pk_bf16_f32") == 32
         assert v.count("ds_read_b128") == 16 and v.count("ds_read_b64_tr_b16") == 32
         assert v.count("buffer_load_dwordx4") == 8 and v.count("s_add_u32 m0") == 8

@@ -45,10 +45,23 @@ class Rnd:
     qpre_con: bool = True   # the same for the C concept rows
     xm_q: bool = True       # the LN-modulate output AS SEEN BY the q third of the qkv projection (a hi+lo bf16 split of
                             # that operand would make it effectively fp32)
+    qk_mode: str = ""       # "" = as `qkv` says; else the storage type of the rotated q / k: "bf16" | "fp16" | "fp32"
+    v_mode: str = ""        # the same for v ("split" = hi + lo bf16 planes, ~16 mantissa bits)
 
 
 def r(x, on):
     return x.bfloat16().float() if on else x
+
+
+def rm(x, mode, default_on):
+    if mode == "":
+        return r(x, default_on)
+    if mode == "fp16":
+        return x.half().float()
+    if mode == "split":
+        hi = x.bfloat16().float()
+        return hi + (x - hi).bfloat16().float()
+    return r(x, mode == "bf16")
 
 
 def sdpa_r(q, k, v, cfg):
@@ -71,16 +84,16 @@ def double_block(sd, pfx, nh, img, txt, vec, rope_ti, con, cvec, rope_ci, cfg):
         if cfg.xm and not cfg.xm_q:
             q = O._split_heads(O.linear(sd, pfx + s + "_attn.qkv", xm32), nh)[0]
         return (O.rms_norm(q, sd[pfx + s + "_attn.norm.query_norm.scale"]),
-                O.rms_norm(k, sd[pfx + s + "_attn.norm.key_norm.scale"]), r(v, cfg.qkv))
+                O.rms_norm(k, sd[pfx + s + "_attn.norm.key_norm.scale"]), rm(v, cfg.v_mode, cfg.qkv))
     iq, ik, iv = pre(img, im, "img")
     tq, tk, tv = pre(txt, tm, "txt")
     cq, ck, cv = pre(con, cm, "txt")
-    q = r(O.apply_rope(torch.cat((tq, iq), 2), *rope_ti), cfg.qkv)
-    k = r(O.apply_rope(torch.cat((tk, ik), 2), *rope_ti), cfg.qkv)
+    q = rm(O.apply_rope(torch.cat((tq, iq), 2), *rope_ti), cfg.qk_mode, cfg.qkv)
+    k = rm(O.apply_rope(torch.cat((tk, ik), 2), *rope_ti), cfg.qk_mode, cfg.qkv)
     attn = sdpa_r(q, k, torch.cat((tv, iv), 2), cfg)
     t_attn, i_attn = r(attn[:, :, :T], cfg.attn), r(attn[:, :, T:], cfg.attn)
-    qc = r(O.apply_rope(torch.cat((cq, iq), 2), *rope_ci), cfg.qkv)
-    kc = r(O.apply_rope(torch.cat((ck, ik), 2), *rope_ci), cfg.qkv)
+    qc = rm(O.apply_rope(torch.cat((cq, iq), 2), *rope_ci), cfg.qk_mode, cfg.qkv)
+    kc = rm(O.apply_rope(torch.cat((ck, ik), 2), *rope_ci), cfg.qk_mode, cfg.qkv)
     c_attn32 = sdpa_r(qc[:, :, :C], kc, torch.cat((cv, iv), 2), cfg)   # fp32 copy feeds the maps
     t_attn, i_attn, c_attn32 = map(O._merge_heads, (t_attn, i_attn, c_attn32))
     d = {"output_space_concept_vectors": c_attn32, "output_space_image_vectors": i_attn,
@@ -124,8 +137,17 @@ def main():
                  Rnd("r4_today+fp32_xm+fp32_qkv", **dict(now, xm=False), qkv=False),
                  Rnd("r4_today+fp32_hid", **now, hid=False),
                  Rnd("r4_today+fp32_xm+fp32_qkv+fp32_p", **dict(now, xm=False), qkv=False, p=False)]
+    out_space2 = [Rnd("r4_today", **now),
+                  Rnd("r4_fp32_qk", **now, qk_mode="fp32"),
+                  Rnd("r4_fp32_v", **now, v_mode="fp32"),
+                  Rnd("r4_fp16_qk", **now, qk_mode="fp16"),
+                  Rnd("r4_fp16_qk+split_v", **now, qk_mode="fp16", v_mode="split"),
+                  Rnd("r4_fp16_qk+fp16_v", **now, qk_mode="fp16", v_mode="fp16"),
+                  Rnd("r4_split_v", **now, v_mode="split")]
     if len(sys.argv) > 1 and sys.argv[1] == "--out-space":
         variants, sys.argv = out_space, sys.argv[:1] + sys.argv[2:]
+    if len(sys.argv) > 1 and sys.argv[1] == "--out-space2":
+        variants, sys.argv = out_space2, sys.argv[:1] + sys.argv[2:]
     if len(sys.argv) > 1:
         variants = [v for v in variants if v.name.split("(")[0] in sys.argv[1:]]
     nh = p.num_heads

@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 B, T, Li, NH = 5, 256, 4096, 24
 H = NH * 128
 SL2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
-KINDS = ["std1", "std4", "std8", "std16", "structured"]
+KINDS = ["std1", "std4", "std8", "std16", "std24", "structured", "structured_far"]
 
 
 def make(kind, dev):
@@ -42,9 +42,10 @@ def make(kind, dev):
         k = torch.randn(n, NH, 128, device=dev, generator=g) * 0.05
         for j in range(B):
             t0 = j * T                                   # item j's text rows come first in its key order
-            k[t0:t0 + 64] += u[None] * (-20.0 * math.sqrt(128.0) / qs)
+            far = kind == "structured_far"     # -40 / +45 nats: 123 octaves, beyond what ONE fp32 reference can span
+            k[t0:t0 + 64] += u[None] * ((-40.0 if far else -20.0) * math.sqrt(128.0) / qs)
             hot = B * T + j * Li + torch.randperm(Li, device=dev, generator=g)[:5]
-            k[hot] += u[None] * (25.0 * math.sqrt(128.0) / qs)
+            k[hot] += u[None] * ((45.0 if far else 25.0) * math.sqrt(128.0) / qs)
     v = torch.randn(n, NH, 128, device=dev, generator=g)
     return q.reshape(n, H), k.reshape(n, H).bfloat16(), v.reshape(n, H).bfloat16()
 
@@ -99,13 +100,15 @@ def main():
     doc = {"shape": f"{B} problems x ({T} + {Li}) rows, {NH} heads, head_dim 128, q pre-scaled (ca_attn4_kernel)",
            "method": "best of 3 x 10 launches after 2 warm-ups (HIP events); counters of ONE launch (ca_attn_stats); error on "
                      "320 query rows x 2 heads of item 0 against an fp32 softmax of the same bf16 inputs"}
-    for mode, env in (("rereference(default)", {}), ("no_rereference(CA_ATTN_REREF=0, round-3 behaviour)",
-                                                      {"CA_ATTN_REREF": "0"})):
+    for mode, env in (("default(limit 2^100, in-place re-reference above 2^64)", {}),
+                      ("no_rereference(CA_ATTN_REREF=0, limit 2^100)", {"CA_ATTN_REREF": "0"}),
+                      ("round3(CA_ATTN_REREF=0 CA_ATTN_LIMIT60=1: limit 2^60, recomputation only)",
+                       {"CA_ATTN_REREF": "0", "CA_ATTN_LIMIT60": "1"})):
         tmp = out + "." + mode.split("(")[0] + ".tmp"
         subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", tmp], check=True, env=dict(os.environ, **env))
         doc[mode] = json.load(open(tmp))
         os.remove(tmp)
-    base = doc["rereference(default)"]["std1"]["us_per_launch"]
+    base = doc["default(limit 2^100, in-place re-reference above 2^64)"]["std1"]["us_per_launch"]
     doc["slowdown_vs_std1"] = {m: {k: doc[m][k]["us_per_launch"] / base for k in KINDS}
                                for m in doc if isinstance(doc[m], dict) and "std1" in doc[m]}
     json.dump(doc, open(out, "w"), indent=1)

@@ -35,6 +35,7 @@ KO = set(filter(None, os.environ.get("CA_A4_KO", "").split(",")))
 ORDER = os.environ.get("CA_A4_ORDER", "split")
 
 AO, AQ, AK, AV = 0, 128, 192, 224
+QK_T = '" CA_A4_QK_T "'   # spliced into the asm string literal: ..."v_mfma_f32_32x32x16_" CA_A4_QK_T " %0, ..."
 TILE = 16384
 V_BASE_IN_ADDR = True   # the V address registers already contain the V ring's base
 
@@ -210,10 +211,12 @@ def gen_iteration(r):
             kb, ks, qb = s >> 4, (s >> 1) & 7, s & 1
             a = areg(AK + 4 * ks, 4)
             q = areg(AQ + 4 * (qb * 8 + ks), 4)
+            # (the K Q^T MFMAs take their operand type from the including kernel: CA_A4_QK_T = "bf16", or "f16" for the
+            # variant whose q / k rows were written as IEEE half by the qkv epilogue -- same layout, same rate)
             if ks == 0:
-                st.ins(f"v_mfma_f32_32x32x16_bf16 {{0}}, {a}, {q}, {{1}}", (S(kb, qb), "w"), (f"NM{qb}", "r"))
+                st.ins(f"v_mfma_f32_32x32x16_{QK_T} {{0}}, {a}, {q}, {{1}}", (S(kb, qb), "w"), (f"NM{qb}", "r"))
             else:
-                st.ins(f"v_mfma_f32_32x32x16_bf16 {{0}}, {a}, {q}, {{0}}", (S(kb, qb), "rw"))
+                st.ins(f"v_mfma_f32_32x32x16_{QK_T} {{0}}, {a}, {q}, {{0}}", (S(kb, qb), "rw"))
         else:
             f, qb = (s - 32) >> 1, (s - 32) & 1
             kb, sk, db = f >> 3, (f >> 2) & 1, f & 3
@@ -346,11 +349,11 @@ def gen_helpers():
                 for ks in range(8):
                     a, q = areg(AK + 4 * ks, 4), areg(AQ + 4 * (qb * 8 + ks), 4)
                     if ks == 0 and zero:
-                        L.append(f'  asm volatile("v_mfma_f32_32x32x16_bf16 %0, {a}, {q}, 0" : "=v"({S(kb, qb)})); \\')
+                        L.append(f'  asm volatile("v_mfma_f32_32x32x16_{QK_T} %0, {a}, {q}, 0" : "=v"({S(kb, qb)})); \\')
                     elif ks == 0:
-                        L.append(f'  asm volatile("v_mfma_f32_32x32x16_bf16 %0, {a}, {q}, %1" : "=&v"({S(kb, qb)}) : "v"(NM{qb})); \\')
+                        L.append(f'  asm volatile("v_mfma_f32_32x32x16_{QK_T} %0, {a}, {q}, %1" : "=&v"({S(kb, qb)}) : "v"(NM{qb})); \\')
                     else:
-                        L.append(f'  asm volatile("v_mfma_f32_32x32x16_bf16 %0, {a}, {q}, %0" : "+v"({S(kb, qb)})); \\')
+                        L.append(f'  asm volatile("v_mfma_f32_32x32x16_{QK_T} %0, {a}, {q}, %0" : "+v"({S(kb, qb)})); \\')
             if kb == 0:   # the ring is re-filled for key block 1: the MFMAs above must have read their operands
                 L.append('  asm volatile("s_nop 7"); \\')
         L.append('  asm volatile("s_nop 15\\n\\ts_nop 7" : "+v"(S00), "+v"(S01), "+v"(S10), "+v"(S11)); } while (0)')
