@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CA_LIB_PATH: another build of the same library (A/B and diagnostic builds under tools/ab_libs); still no fallback
 LIB_PATH = os.environ.get("CA_LIB_PATH") or os.path.join(_HERE, "libconceptattn.so")
 
-CA_VERSION = 123
+CA_VERSION = 124
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU, EPI_QKV_NORM_ROPE = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_256x256, TILE_256x192, TILE_256x128, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_PP_256x256, TILE_PP_256x128, TILE_PP_256x192 = 5, 6, 7
@@ -78,6 +78,8 @@ SIGNATURES = {
                                              C.c_void_p]),
     "ca_qpre_finish_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_void_p]),
+    "ca_qpre_finish_rope_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ca_quantize_rows_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p]),
     "ca_qknorm_rope_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(NormSegment),

@@ -416,8 +416,14 @@ __global__ __launch_bounds__(256) void ca_gemv_kernel(const float *__restrict__ 
 // projection before its RMS norm (what CA_EPI_QKV_NORM_ROPE stores to q_prerope with qpre_f32 = 2), d = the product
 // of the LayerNorm output's low plane with the same weights: the sum is the projection of the UNROUNDED LayerNorm
 // output to ~16 mantissa bits.  16 lanes per (row, head), 8 columns each.
+// (round 4) With `rope` and `q_out` the normalised vector is also rotated (apply_rope, flux/math.py:25-30), multiplied by
+// q_out_scale and stored as the ATTENTION's q (bf16, or IEEE half with q_f16) -- exactly what the qkv epilogue does with
+// the projection of bf16(y), but from the projection of the unrounded y: the bf16 rounding of that GEMM operand, as it
+// reaches q, is what bounds a single output-space heat map (tests/tools/diag_out_space.py: 7.7e-4 of 7.8e-4).
 __global__ __launch_bounds__(256) void ca_qpre_finish_kernel(float *__restrict__ x, int ldx, const float *__restrict__ d,
-                                                             int ldd, const bf16 *__restrict__ scale, int M, int heads) {
+                                                             int ldd, const bf16 *__restrict__ scale, int M, int heads,
+                                                             const float *__restrict__ rope, void *__restrict__ q_out,
+                                                             int ldq, float q_out_scale, int q_f16) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long unit = gid >> 4;           // (row, head)
   const int t16 = (int)(gid & 15);
@@ -447,6 +453,23 @@ __global__ __launch_bounds__(256) void ca_qpre_finish_kernel(float *__restrict__
   }
   *(f32x4 *)xp = a0;
   *(f32x4 *)(xp + 4) = a1;
+  if (q_out) {
+    const float *rp = rope + (size_t)row * 128 + t16 * 8;   // [64 pairs][cos, sin]: pairs 4 t16 .. 4 t16 + 3
+    const f32x4 r0 = *(const f32x4 *)rp, r1 = *(const f32x4 *)(rp + 4);
+    const float y[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const float cs[4] = {r0[0], r0[2], r1[0], r1[2]}, sn[4] = {r0[1], r0[3], r1[1], r1[3]};
+    const float qos = q_out_scale == 0.0f ? 1.0f : q_out_scale;
+    float z[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // (the expressions of the qkv epilogue, ca_gemm.hip)
+      z[2 * i] = __builtin_fmaf(cs[i], y[2 * i], -(sn[i] * y[2 * i + 1])) * qos;
+      z[2 * i + 1] = __builtin_fmaf(sn[i], y[2 * i], cs[i] * y[2 * i + 1]) * qos;
+    }
+    uint4 o;
+    if (q_f16) o = make_uint4(ca_pack2_f16(z[0], z[1]), ca_pack2_f16(z[2], z[3]), ca_pack2_f16(z[4], z[5]), ca_pack2_f16(z[6], z[7]));
+    else o = make_uint4(ca_pack2(z[0], z[1]), ca_pack2(z[2], z[3]), ca_pack2(z[4], z[5]), ca_pack2(z[6], z[7]));
+    *(uint4 *)((char *)q_out + ((size_t)row * ldq + head * 128 + t16 * 8) * 2) = o;
+  }
 }
 
 // logits[c,p] = <img_vec[p,:], con_vec[c,:]> for CC concepts per pass; one wave per patch.
@@ -892,17 +915,28 @@ extern "C" int ca_heatmap_logits_bf16(const void *img_vec, int32_t ldi, const vo
   return CA_OK;
 }
 
-extern "C" int ca_qpre_finish_f32(float *x, int32_t ldx, const float *d, int32_t ldd, const void *norm_scale, int32_t M,
-                                  int32_t heads, ca_stream_t stream) {
+extern "C" int ca_qpre_finish_rope_f32(float *x, int32_t ldx, const float *d, int32_t ldd, const void *norm_scale,
+                                       const float *rope, void *q_out, int32_t ldq, float q_out_scale, int32_t q_f16,
+                                       int32_t M, int32_t heads, ca_stream_t stream) {
   if (!x || !norm_scale || M < 1 || heads < 1 || ldx % 4 || ldx < heads * 128 || (d && (ldd % 4 || ldd < heads * 128)) ||
       (((uintptr_t)x | (uintptr_t)d | (uintptr_t)norm_scale) & 15)) {
     ca_set_error("ca_qpre_finish_f32: bad arguments (M=%d heads=%d ldx=%d ldd=%d)", M, heads, ldx, ldd);
     return CA_ERR_ARG;
   }
+  if (q_out && (!rope || ldq % 8 || ldq < heads * 128 || (((uintptr_t)rope | (uintptr_t)q_out) & 15) ||
+                !(q_out_scale >= 0.0f) || (q_f16 != 0 && q_f16 != 1))) {
+    ca_set_error("ca_qpre_finish_rope_f32: q_out needs rope [M,64,2], ldq %% 8 == 0, ldq >= heads*128, 16-byte alignment");
+    return CA_ERR_ARG;
+  }
   const long threads = (long)M * heads * 16;
   hipLaunchKernelGGL(ca_qpre_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     x, ldx, d, ldd, (const bf16 *)norm_scale, M, heads);
+                     x, ldx, d, ldd, (const bf16 *)norm_scale, M, heads, rope, q_out, ldq, q_out_scale, q_f16);
   return check_launch("ca_qpre_finish_f32");
+}
+
+extern "C" int ca_qpre_finish_f32(float *x, int32_t ldx, const float *d, int32_t ldd, const void *norm_scale, int32_t M,
+                                  int32_t heads, ca_stream_t stream) {
+  return ca_qpre_finish_rope_f32(x, ldx, d, ldd, norm_scale, nullptr, nullptr, 0, 0.0f, 0, M, heads, stream);
 }
 
 extern "C" int ca_heatmap_softmax_accumulate(const float *logits, int32_t C, int32_t L, float weight, float *acc,

@@ -225,6 +225,7 @@ class HipFluxDiT:
         # fp16's range.  "all" (default): every block, so that the image does not depend on which layers are
         # captured; "captured": only the layers whose maps are requested; "0": bf16 as the reference (A/B aid).
         # Needs the pre-scaled-q kernel (CA_ATTN_PRESCALE / CA_ATTN_KERNEL=8 switch it off).
+        self.split_q_attention = os.environ.get("CA_SPLIT_Q_ATTENTION", "1") != "0"
         self.qk_f16 = os.environ.get("CA_QK_F16", "all")
         if self.qk_f16 not in ("all", "captured", "0"):
             raise ValueError("CA_QK_F16 must be all, captured or 0")
@@ -663,8 +664,15 @@ class HipFluxDiT:
                              q_prerope=None if qpre is None else qpre[:oI], q_out_scale=self._q_out_scale(),
                              qpre_raw=split, qk_f16=qk16)])
         if split:
-            ops.qpre_finish(qpre[oI:], self.QD[oI:], W[b + "img_attn.norm.query_norm.scale"], NH)
-            ops.qpre_finish(qpre[:oT], self.QD[:oT], W[b + "txt_attn.norm.query_norm.scale"], NH)
+            # ... and (round 4) the ATTENTION's q of those rows from the same unrounded projection: rotated, scaled and
+            # stored over what the epilogue wrote.  A single output-space map: 7.8e-4 -> 2.5e-4 from the fp32 oracle
+            # (the operand's rounding reaches the map through q; tests/tools/diag_out_space.py).  The image therefore
+            # depends, at rounding level, on which layers' maps are requested; CA_SPLIT_Q_ATTENTION=0 restores q.
+            sq = dict(q_out_scale=self._q_out_scale(), q_f16=qk16) if self.split_q_attention else {}
+            ops.qpre_finish(qpre[oI:], self.QD[oI:], W[b + "img_attn.norm.query_norm.scale"], NH,
+                            **(dict(rope=self.ROPE[oI:], q_out=qs[oI:], **sq) if sq else {}))
+            ops.qpre_finish(qpre[:oT], self.QD[:oT], W[b + "txt_attn.norm.query_norm.scale"], NH,
+                            **(dict(rope=self.ROPE[:oT], q_out=qs[:oT], **sq) if sq else {}))
         # K8+K9: per item, joint text+image attention and the concept rows; one launch (concept problems first)
         probs = []
         for j in range(B):

@@ -280,8 +280,11 @@ def ln_modulate(x, out, segments, eps: float = 1e-6, out_scale=None, out_lo=None
                arr, len(segments), eps, _stream()), "ca_ln_modulate_bf16")
 
 
-def qpre_finish(x, d, norm_scale, num_heads: int) -> None:
-    """x <- RMSNorm_128(x + d) * norm_scale per (row, head), in place; x, d fp32 [M, heads*128] (d may be None)."""
+def qpre_finish(x, d, norm_scale, num_heads: int, rope=None, q_out=None, q_out_scale: float = 0.0,
+                q_f16: bool = False) -> None:
+    """x <- RMSNorm_128(x + d) * norm_scale per (row, head), in place; x, d fp32 [M, heads*128] (d may be None).
+    With ``rope`` (fp32 [M,64,2]) and ``q_out`` (bf16-typed [M, heads*128] view, row stride free) the result is also
+    rotated, multiplied by ``q_out_scale`` and stored there as the attention's q (IEEE half bits with ``q_f16``)."""
     lib = L.load()
     _chk(x, torch.float32, "x"), _chk(norm_scale, torch.bfloat16, "norm_scale")
     if d is not None:
@@ -290,8 +293,17 @@ def qpre_finish(x, d, norm_scale, num_heads: int) -> None:
             raise ValueError("qpre_finish: d must have x's shape")
     if x.dim() != 2 or x.shape[1] != num_heads * 128 or norm_scale.numel() != 128:
         raise ValueError("qpre_finish: x must be [M, heads*128], norm_scale [128]")
-    L.check(lib.ca_qpre_finish_f32(x.data_ptr(), x.stride(0), _ptr(d), 0 if d is None else d.stride(0),
-                                   norm_scale.data_ptr(), x.shape[0], num_heads, _stream()), "ca_qpre_finish_f32")
+    if q_out is None:
+        L.check(lib.ca_qpre_finish_f32(x.data_ptr(), x.stride(0), _ptr(d), 0 if d is None else d.stride(0),
+                                       norm_scale.data_ptr(), x.shape[0], num_heads, _stream()), "ca_qpre_finish_f32")
+        return
+    _chk(q_out, torch.bfloat16, "q_out"), _chk(rope, torch.float32, "rope")
+    if tuple(q_out.shape) != tuple(x.shape) or tuple(rope.shape) != (x.shape[0], 64, 2) or not rope.is_contiguous():
+        raise ValueError("qpre_finish: q_out must have x's shape, rope must be contiguous [M,64,2]")
+    L.check(lib.ca_qpre_finish_rope_f32(x.data_ptr(), x.stride(0), _ptr(d), 0 if d is None else d.stride(0),
+                                        norm_scale.data_ptr(), rope.data_ptr(), q_out.data_ptr(), q_out.stride(0),
+                                        float(q_out_scale), int(bool(q_f16)), x.shape[0], num_heads, _stream()),
+            "ca_qpre_finish_rope_f32")
 
 
 def quantize_rows_fp8(x, out=None, out_scale=None):

@@ -28,9 +28,9 @@
 extern "C" {
 #endif
 
-#define CA_VERSION 123 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
+#define CA_VERSION 124 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
                           CA_ATTN_Q_PRESCALED; .1: ca_axpy_f32, ca_split_bf16; .2: ca_attn_stats; .3: ca_gemm_problem.qk_f16,
-                          ca_attn_fwd_qk16 */
+                          ca_attn_fwd_qk16; .4: ca_qpre_finish_rope_f32 */
 
 #define CA_OK 0
 #define CA_ERR_ARG (-1)    /* bad shape / null pointer / misalignment */
@@ -256,6 +256,14 @@ int ca_gemv_bf16(const float *x, int32_t nv, int32_t ldx, const void *W, const v
  * GEMM operand is ~90 % of the cross-space heat-map error of a bf16 MFMA path. */
 int ca_qpre_finish_f32(float *x, int32_t ldx, const float *d, int32_t ldd, const void *norm_scale, int32_t M,
                        int32_t heads, ca_stream_t stream);
+/* The same, and with q_out != NULL the normalised vector is also rotated (rope fp32 [M,64,2] for these rows:
+ * apply_rope, flux/math.py:25-30), multiplied by q_out_scale (0 = 1) and stored as 2-byte elements (bf16, or IEEE half
+ * with q_f16 = 1; row stride ldq elements) -- i.e. it REPLACES the attention's q rows that the qkv epilogue formed from
+ * bf16(y) by the ones formed from the unrounded y.  The bf16 rounding of that GEMM operand, through q, is what bounds a
+ * single output-space heat map (modified_double_stream_block.py:112-116 feeding :185-188): 7.7e-4 of 7.8e-4. */
+int ca_qpre_finish_rope_f32(float *x, int32_t ldx, const float *d, int32_t ldd, const void *norm_scale,
+                            const float *rope, void *q_out, int32_t ldq, float q_out_scale, int32_t q_f16,
+                            int32_t M, int32_t heads, ca_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Concept heat maps, one (timestep, layer) at a time (compute_heatmaps_from_vectors,

@@ -36,14 +36,22 @@ REPORT = {}
 # q vectors come from the unrounded LayerNorm output (HipFluxDiT.split_q_capture); at steps >= 1 of a generation the
 # latent itself has moved (pred: 0.24-0.37 % rms off the fp32 trajectory after 57 bf16 blocks per step) and the
 # cross-space logits amplify that: 2-4e-3 per map, 1.07e-3 for the 16-map mean.
-FINAL_OUT_BOUND = 4.7e-4          # schnell 4 steps: 3.15e-4; dev 2 steps: 2.2e-4   (fp32 Euler state, hi/lo img_in, fp32 pred, fp32 image vectors: round 3)
-FINAL_CROSS_BOUND = 2.5e-4        # schnell 4 steps: 1.65e-4 (bf16 Euler state: 1.05e-3); dev 2 steps: 1.15e-4; encode: 1.6e-4
-SINGLE_OUT_BOUND = 2.8e-3         # any (step, layer): <= 1.80e-3; step 0: <= 1.58e-3; encode layer 0: 1.90e-3
-SINGLE_OUT_STEP0_BOUND = 2.2e-3
+# Round 4 (profiles/r04_full_depth_parity.json): the attention's q of the captured layers comes from the unrounded
+# LayerNorm output as well and q / k are stored as IEEE half: every single (step, layer) map of every configuration is
+# now inside the north star's 1e-3 in BOTH spaces (output space: 1.80e-3 -> 5.6e-4).
+FINAL_OUT_BOUND = 1.4e-4          # schnell 4 steps: 8.9e-5 (round 3: 3.15e-4); dev 2 steps: 6.0e-5
+FINAL_CROSS_BOUND = 2.7e-4        # schnell 4 steps: 1.77e-4 (bf16 Euler state: 1.05e-3); dev 2 steps: 1.03e-4; encode: 1.5e-4
+SINGLE_OUT_BOUND = 8.4e-4         # any (step, layer): <= 5.6e-4 (round 3: 1.80e-3); encode layer 0: 5.3e-4
+SINGLE_OUT_STEP0_BOUND = 5.7e-4   # step 0, all 19 layers: 2.2e-4 - 3.8e-4 (round 3: 1.0e-3 - 1.6e-3)
+CAPTURE_SET_BOUND = 4.5e-4        # a map of layers 15-18 when ALL 19 layers are captured vs only 15-18: <= 3e-4 (below)
 SINGLE_CROSS_BOUND = 1.15e-3      # any (step, layer): <= 7.7e-4 (bf16 Euler state: 4.3e-3)
 SINGLE_CROSS_SAME_INPUT_BOUND = 6.3e-4   # step 0 / encode path (the oracle's own input): <= 4.2e-4
-ENCODE_FINAL_OUT_BOUND = 1.05e-3  # one forward, mean of 4 layers: 6.9e-4
+ENCODE_FINAL_OUT_BOUND = 3.3e-4   # one forward, mean of 4 layers: 2.2e-4 (round 3: 6.9e-4)
 ENCODE_FINAL_CROSS_BOUND = 2.5e-4 # 1.6e-4
+# fp8 mode (opt-in, never the headline) against the fp32 oracle; bounds to be read next to the measured values
+FP8_OUT_VS_ORACLE_BOUND = 6e-2
+FP8_CROSS_VS_ORACLE_BOUND = 0.12
+FP8_ARGMAX_VS_ORACLE_BOUND = 0.90
 
 
 def bf_inputs(p, size, T, C):
@@ -62,9 +70,10 @@ def pipe():
     json.dump(REPORT, open(os.path.join(ROOT, "gpurun_out", "full_depth_parity.json"), "w"), indent=1)
 
 
-def run_steps(pl, inp, steps, per_layer=True, ts=None, guidance=0.0):
+def run_steps(pl, inp, steps, per_layer=True, ts=None, guidance=0.0, layers=None):
     """The Euler loop of sampling.denoise_steps with one per-layer table per step (fused heat-map path).
-    ``ts``: explicit schedule (steps + 1 values), e.g. the head of flux-dev's shifted 50-step schedule."""
+    ``ts``: explicit schedule (steps + 1 values), e.g. the head of flux-dev's shifted 50-step schedule.
+    ``layers``: the double blocks whose maps are requested (default all; the other rows of the tables stay 0)."""
     m, p = pl.model, pl.params
     d = {k: v.to(DEV) for k, v in inp.items()}
     x = d["latent"].to(torch.bfloat16)
@@ -79,8 +88,9 @@ def run_steps(pl, inp, steps, per_layer=True, ts=None, guidance=0.0):
     lat32 = img.float() if getattr(m, "fp32_latent", False) else None    # the Euler state as sampling.denoise_steps keeps it
     m.precompute_conditioning(ts[:-1], prep["vec"], con_vec, guidance)
     for s, (tc, tp) in enumerate(zip(ts[:-1], ts[1:])):
-        req = HeatmapRequest(tuple(range(p.depth)), 0.0, torch.zeros(C, L_, device=DEV), torch.zeros(C, L_, device=DEV),
-                             per_layer_out=out[s], per_layer_cross=cross[s], per_layer_weight=1.0)
+        req = HeatmapRequest(tuple(range(p.depth) if layers is None else layers), 0.0, torch.zeros(C, L_, device=DEV),
+                             torch.zeros(C, L_, device=DEV), per_layer_out=out[s], per_layer_cross=cross[s],
+                             per_layer_weight=1.0)
         pred, _ = m(img=img if lat32 is None else lat32, img_ids=prep["img_ids"], txt=prep["txt"], txt_ids=prep["txt_ids"], concepts=con,
                     concept_ids=con_ids, concept_vec=con_vec, y=prep["vec"],
                     timesteps=torch.full((1,), tc, device=DEV), guidance=torch.full((1,), guidance, device=DEV),
@@ -142,11 +152,29 @@ def test_four_steps_full_depth_vs_fp32_golden_with_reference_bf16_yardstick(pipe
     assert max(v[0] for v in rep["out"].values()) <= SINGLE_OUT_BOUND
     assert max(v[0] for v in rep["cross"].values()) <= SINGLE_CROSS_BOUND
     assert rep["final_latent_rel_rms"] <= max(0.02, rep["reference_bf16_final_latent_rel_rms"])
-    # the product entry point gives the same final maps as the per-layer tables (same kernels, same order)
+    # the product entry point gives the same final maps as per-layer tables of the SAME captured layers (same kernels,
+    # same order).  The captured set matters at rounding level since round 4: in a captured layer the attention's q of the
+    # image and concept rows is formed from the unrounded LayerNorm output (HipFluxDiT.split_q_attention), so a run that
+    # captures all 19 layers carries slightly different residual rows into layers 15-18 than one that captures only those.
     d = {k: v.to(DEV) for k, v in inp.items()}
     _, hm, cm = pipe.generate_on_device(d["latent"], d["txt"].bfloat16(), d["vec"].bfloat16(), d["concepts"].bfloat16())
-    assert np.abs(hm[0].reshape(4, -1).cpu().numpy() - out[:, 15:19].mean((0, 1))).max() < 1e-5
-    assert np.abs(cm[0].reshape(4, -1).cpu().numpy() - cross[:, 15:19].mean((0, 1))).max() < 1e-5
+    out4, cross4, _, _ = run_steps(pipe, inp, 4, layers=range(15, 19))
+    assert np.abs(hm[0].reshape(4, -1).cpu().numpy() - out4[:, 15:19].mean((0, 1))).max() < 1e-5
+    assert np.abs(cm[0].reshape(4, -1).cpu().numpy() - cross4[:, 15:19].mean((0, 1))).max() < 1e-5
+    dep = [float(np.abs(out4[:, 15:19] - out[:, 15:19]).max()), float(np.abs(cross4[:, 15:19] - cross[:, 15:19]).max())]
+    REPORT["four_steps"]["capture_set_dependence_layers_15_18(out,cross)"] = dep
+    assert max(dep) <= CAPTURE_SET_BOUND, dep
+    # ... and the maps of the product's own capture set are inside the same bounds
+    fo4 = float(np.abs(out4[:, 15:19].mean((0, 1)) - g["final_out"]).max())
+    fc4 = float(np.abs(cross4[:, 15:19].mean((0, 1)) - g["final_cross"]).max())
+    REPORT["four_steps"]["final_capturing_15_18_only"] = {"out": fo4, "cross": fc4}
+    assert fo4 <= FINAL_OUT_BOUND and fc4 <= FINAL_CROSS_BOUND, (fo4, fc4)
+    for s_ in range(4):
+        for l in range(15, 19):
+            go = g["out_step0"][l] if s_ == 0 else g["out_late"][s_ - 1, l - 15]
+            gc = g["cross_step0"][l] if s_ == 0 else g["cross_late"][s_ - 1, l - 15]
+            assert float(np.abs(out4[s_, l] - go).max()) <= SINGLE_OUT_BOUND, (s_, l)
+            assert float(np.abs(cross4[s_, l] - gc).max()) <= SINGLE_CROSS_BOUND, (s_, l)
 
 
 def dev_items(p, n, size=1024, T=256, C=4, first_seed=5):
@@ -245,7 +273,19 @@ def test_encode_path_full_size_vs_fp32_golden(pipe, golden):
     rep["final"] = {"out": [fo, float(y["final_err_out_fp32reduce"])], "cross": [fc, float(y["final_err_cross_fp32reduce"])]}
     REPORT["encode_full"] = rep
     print("encode full size:", rep)
-    assert np.abs(ho[0].reshape(C, -1).cpu().numpy() - out[15:19].mean(0)).max() < 1e-5
+    # (against tables of the same captured layers: see the four-step test for why the captured set matters)
+    out4 = torch.zeros(p.depth, C, L_, device=DEV)
+    cross4 = torch.zeros(p.depth, C, L_, device=DEV)
+    req4 = HeatmapRequest(tuple(range(15, 19)), 0.0, torch.zeros(C, L_, device=DEV), torch.zeros(C, L_, device=DEV),
+                          per_layer_out=out4, per_layer_cross=cross4, per_layer_weight=1.0)
+    m(img=prep["img"], img_ids=prep["img_ids"], txt=prep["txt"], txt_ids=prep["txt_ids"], concepts=con,
+      concept_ids=con_ids, concept_vec=con_vec, y=con_vec, timesteps=torch.full((1,), t, device=DEV),
+      guidance=torch.zeros(1, device=DEV), stop_after_multimodal_attentions=True, return_vectors=False, heatmaps=req4)
+    torch.cuda.synchronize()
+    assert np.abs(ho[0].reshape(C, -1).cpu().numpy() - out4[15:19].mean(0).cpu().numpy()).max() < 1e-5
+    assert np.abs(out4[15:19].cpu().numpy() - out[15:19]).max() <= CAPTURE_SET_BOUND
+    for li, l in enumerate(range(15, 19)):
+        assert float(np.abs(out4[l].cpu().numpy() - g["out_layers"][li]).max()) <= SINGLE_OUT_BOUND, l
     assert fo <= max(1e-3, float(y["final_err_out_fp32reduce"])) and fo <= ENCODE_FINAL_OUT_BOUND
     assert fc <= max(1e-3, float(y["final_err_cross_fp32reduce"])) and fc <= ENCODE_FINAL_CROSS_BOUND
 
@@ -340,6 +380,56 @@ def test_config1_shape_at_full_hidden_size(pipe, golden):
         assert e <= 3e-2 * max(s, 1.0)
     assert rep["pred_rel_rms"] < 0.03
     assert rep["attn_rows_maxabs"] < 1e-2
+
+
+def test_fp8_forward_full_size_vs_fp32_oracle(pipe, golden):
+    """BASELINE.json configs[4] names fp8; the reference has none, so round 3 only compared the fp8 sweep with the bf16
+    sweep of the same kernels.  tests/golden/encode_full.npz holds the fp32 ORACLE's maps of layers 0, 9, 15-18 for
+    exactly such a forward (one noised image, the 19 double blocks, C = 2): the same forward with every projection in
+    e4m3 against them.  fp8 is the opt-in reduced-precision mode, not the parity path: the bound states what was
+    measured (profiles/r04_full_depth_parity.json, "fp8_vs_oracle"), the bf16 path's figure is printed beside it."""
+    g = golden("encode_full.npz")
+    p = pipe.params
+    C = 2
+    inp = bf_inputs(p, 1024, 256, C)
+    noise = torch.randn(inp["latent"].shape, generator=torch.Generator().manual_seed(int(g["noise_seed"]))).bfloat16()
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    t = float(g["t"])
+    x = (t * noise.to(DEV).float() + (1.0 - t) * d["latent"].bfloat16().float()).to(torch.bfloat16)
+    con, con_ids, con_vec = sampling.concept_inputs(d["concepts"].bfloat16(), d["vec"].bfloat16())
+    prep = sampling.prepare_from_embeddings(x, d["txt"].bfloat16(), d["vec"].bfloat16())
+    L_ = prep["img"].shape[1]
+    m = pipe.model
+
+    def tables():
+        out = torch.zeros(p.depth, C, L_, device=DEV)
+        cross = torch.zeros(p.depth, C, L_, device=DEV)
+        req = HeatmapRequest(tuple(range(p.depth)), 0.0, torch.zeros(C, L_, device=DEV), torch.zeros(C, L_, device=DEV),
+                             per_layer_out=out, per_layer_cross=cross, per_layer_weight=1.0)
+        m(img=prep["img"], img_ids=prep["img_ids"], txt=prep["txt"], txt_ids=prep["txt_ids"], concepts=con,
+          concept_ids=con_ids, concept_vec=con_vec, y=con_vec, timesteps=torch.full((1,), t, device=DEV),
+          guidance=torch.zeros(1, device=DEV), stop_after_multimodal_attentions=True, return_vectors=False, heatmaps=req)
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), cross.cpu().numpy()
+    b_out, b_cross = tables()
+    m.set_precision("fp8")
+    try:
+        f_out, f_cross = tables()
+    finally:
+        m.set_precision("bf16")
+    rep = {}
+    for li, l in list(enumerate(range(15, 19))) + [(0, 0), (1, 9)]:
+        go, gc = (g["out_layers"][li], g["cross_layers"][li]) if l >= 15 else (g["out_early"][li], g["cross_early"][li])
+        rep[f"layer{l}"] = {"fp8_out": float(np.abs(f_out[l] - go).max()), "fp8_cross": float(np.abs(f_cross[l] - gc).max()),
+                            "bf16_out": float(np.abs(b_out[l] - go).max()), "bf16_cross": float(np.abs(b_cross[l] - gc).max()),
+                            "fp8_argmax_agree_out": float((f_out[l].argmax(0) == go.argmax(0)).mean()),
+                            "fp8_argmax_agree_cross": float((f_cross[l].argmax(0) == gc.argmax(0)).mean())}
+    REPORT["fp8_vs_oracle"] = rep
+    print("fp8 forward vs the fp32 oracle:", rep)
+    assert np.isfinite(f_out).all() and np.isfinite(f_cross).all()
+    assert max(v["fp8_out"] for v in rep.values()) < FP8_OUT_VS_ORACLE_BOUND
+    assert max(v["fp8_cross"] for v in rep.values()) < FP8_CROSS_VS_ORACLE_BOUND
+    assert min(v["fp8_argmax_agree_out"] for v in rep.values()) > FP8_ARGMAX_VS_ORACLE_BOUND
 
 
 def test_fp8_layer_noise_sweep_full_size_vs_bf16(pipe):

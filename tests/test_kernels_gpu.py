@@ -514,8 +514,10 @@ def test_attention_half_precision_q_and_k(nq, nk, n0):
     prb = ops.Attn(qb, ob, kb[:n0], v[:n0], kb[n0:], v[n0:], out_f32=ob32) if n0 else ops.Attn(qb, ob, kb, v, out_f32=ob32)
     ops.attention([prb], nh, q_prescaled=True)
     ref32 = torch.cat([attn_ref(q32[i:i + 1088], k32, v, nh) for i in range(0, nq, 1088)])
-    e16, eb = (o32 - ref32).abs().max().item(), (ob32 - ref32).abs().max().item()
+    # (rms: what is left with half-precision q / k is the bf16 rounding of P, which both kernels share)
+    e16, eb = (o32 - ref32).pow(2).mean().sqrt().item(), (ob32 - ref32).pow(2).mean().sqrt().item()
     assert e16 < 0.6 * eb, (e16, eb)
+    assert (o32 - ref32).abs().max().item() < (ob32 - ref32).abs().max().item()
     with pytest.raises(ValueError):
         ops.attention([pr], nh, qk_f16=True)          # half-precision q / k exist for pre-scaled q only
 
