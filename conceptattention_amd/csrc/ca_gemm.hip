@@ -1324,6 +1324,19 @@ int tile_n_of(int tile) {
   }
 }
 
+// CU count of the current device (cached per device; a race only repeats the query); -1 if the query fails
+int ca_cu_count() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int n = cus[dev & 63].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
+    cus[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 // Pick the tile that minimises (rounds over the 256 CUs) x (time of one round).  Round times are
 // per 48 K-steps, measured on MI355X (tools/bench_kernels.py): they only need to rank the choices.
 int auto_tile(const ca_gemm_problem *p, int n) {
@@ -1359,7 +1372,20 @@ int auto_tile(const ca_gemm_problem *p, int n) {
     double rounds = work / kmax / 256.0;
     rounds = work == 0 ? 0.0 : rounds <= 1.0 ? 1.0 : (double)(long)(rounds + 0.999);
     // the thin-row launch behind the main one: measured 0.3 of a 256x256 round at its K (profiles/r02_remainder_probe.txt)
-    const double cost = rounds * c.round_us * kmax + 0.3 * c.round_us * thin_k;
+    // -- unless the thin tiles fit into the CUs the main tiles leave idle in their last round (gemm_impl's thin_fits):
+    // then they ride in the walk and cost nothing
+    double thin_cost = 0.3 * c.round_us * thin_k;
+    if (c.tile == CA_TILE_PP_256x256 && thin_k > 0) {
+      long main_t = 0, thin_t = 0;
+      for (int i = 0; i < n; ++i) {
+        const int rem = p[i].M % 256;
+        const int thin = (rem > 0 && rem <= CA_GEMM_THIN_ROWS) ? 1 : 0;
+        main_t += ((p[i].M + 255) / 256 - thin) * (long)(p[i].N / 256);
+        thin_t += thin * (long)(p[i].N / 256);
+      }
+      if (main_t % 256 != 0 && main_t % 256 + thin_t <= 256) thin_cost = 0.0;
+    }
+    const double cost = rounds * c.round_us * kmax + thin_cost;
     if (cost < best_cost) {
       best_cost = cost;
       best = c.tile;
@@ -1496,13 +1522,32 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
     const char *e = getenv("CA_GEMM_THIN_KERNEL");  // 0: thin rows stay 256-column tiles of the ping-pong walk (A/B aid)
     return e ? atoi(e) : 1;
   }();
+  const int n_cu = ca_cu_count();
+  // Thin last row tiles (<= CA_GEMM_THIN_ROWS valid rows) under the bf16 256x256 tile normally get their own launch of
+  // 32 x 128 tiles behind the main one (ca_gemm_thin_kernel).  But when the main tiles leave enough CUs idle in their
+  // last round for every thin tile -- the one-item forward: 204 + 12 tiles on 256 CUs -- the thin tiles ride in the walk
+  // (they are walked last, cost 0.75 of a full tile and finish inside the round that runs anyway): no second launch.
+  // All three forms give the same bits per row (tests/test_kernels_gpu.py: thin rows in-walk / own kernel / full tile).
+  int main_all = 0, thin_all = 0;
+  for (int i = 0; i < n_problems; ++i) {
+    const int rem = L.p[i].M % 256;
+    const int thin = (rem > 0 && rem <= CA_GEMM_THIN_ROWS) ? 1 : 0;
+    main_all += (L.mt[i] - thin) * L.nt[i];
+    thin_all += thin * L.nt[i];
+  }
+  static const int thin_inwalk_env = [] {
+    const char *e = getenv("CA_GEMM_THIN_INWALK");   // 0: thin rows always leave the walk (round 3's behaviour; A/B aid)
+    return e ? atoi(e) : 1;
+  }();
+  const bool thin_fits = thin_inwalk_env && n_cu > 0 && thin_all > 0 && main_all % n_cu != 0 &&
+                         main_all % n_cu + thin_all <= n_cu;
   int total_pp = 0;
   for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i) {  // tile order of the ping-pong kernel: thin last row tiles go last
     const int rem = i < n_problems ? L.p[i].M % 256 : 0;
     const int thin = (rem > 0 && rem <= CA_GEMM_THIN_ROWS) ? 1 : 0;
     // under the bf16 256x256 tile: their own launch of 32 x 128 tiles instead (ca_gemm_thin_kernel), one grid row
     // per 32 rows
-    const bool own = thin && !fp8 && tile == CA_TILE_PP_256x256 && thin_kernel_env;
+    const bool own = thin && !fp8 && tile == CA_TILE_PP_256x256 && thin_kernel_env && !thin_fits;
     L.mt_main[i] = i < n_problems ? L.mt[i] - thin : 1;
     L.ntiles_main[i] = i < n_problems ? L.mt_main[i] * L.nt[i] : 0;
     L.nthin[i] = (thin && !own) ? L.nt[i] : 0;
@@ -1519,14 +1564,7 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
       const char *e = getenv("CA_GEMM_PERSIST");
       return e ? atoi(e) : 1;
     }();
-    static std::atomic<int> cus[64];  // CU count per device, 0 = not asked yet (a race only repeats the query)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    int n = cus[dev & 63].load(std::memory_order_relaxed);
-    if (n == 0) {
-      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
-      cus[dev & 63].store(n, std::memory_order_relaxed);
-    }
+    const int n = n_cu;
     if (persist_env && n > 0 && n % 8 == 0 && total > n) {
       L.persist_tiles = total;
       L.persist_tiles_grid = n;

@@ -226,6 +226,7 @@ class HipFluxDiT:
         # captured; "captured": only the layers whose maps are requested; "0": bf16 as the reference (A/B aid).
         # Needs the pre-scaled-q kernel (CA_ATTN_PRESCALE / CA_ATTN_KERNEL=8 switch it off).
         self.split_q_attention = os.environ.get("CA_SPLIT_Q_ATTENTION", "1") != "0"
+        self.fp8_bf16_qkv_when_captured = os.environ.get("CA_FP8_QKV_BF16_CAPTURED", "1") != "0"
         self.qk_f16 = os.environ.get("CA_QK_F16", "all")
         if self.qk_f16 not in ("all", "captured", "0"):
             raise ValueError("CA_QK_F16 must be all, captured or 0")
@@ -310,11 +311,50 @@ class HipFluxDiT:
             while len(self._ws_cache) >= self.WS_CACHE_ENTRIES:
                 self._ws_cache.pop(next(iter(self._ws_cache)))
         self._ws_cache[key] = cached
-        self.__dict__.update(cached)
+        self.__dict__.update({k: v for k, v in cached.items() if k not in self._LAZY_BUFFERS})
         self._ws_key = key
         self._rope_key = None
 
     WS_CACHE_ENTRIES = 3
+
+    # Buffers only some forwards need (the captured layers' fp32 vectors: ~0.6 GB per work item at 1024 x 1024) are
+    # allocated on first use, per activation set: a model that never returns maps, or runs with CA_SPLIT_Q_CAPTURE=0 /
+    # CA_F32_IMAGE_VECTORS=0 or in fp8 mode, never pays for them.  name -> (rows, columns..., dtype) of the set's geometry
+    _LAZY_BUFFERS = {
+        "QPRE": lambda n, B, T, L, H: ((n, H), torch.float32),       # post-QKNorm pre-RoPE q (cross-space vectors)
+        "XML": lambda n, B, T, L, H: ((n, H), torch.bfloat16),       # low plane of XM: bf16(y - float(bf16(y)))
+        "QD": lambda n, B, T, L, H: ((n, H), torch.float32),         # its q projection (ops.qpre_finish adds it)
+        "ATTI32": lambda n, B, T, L, H: ((B, T + L, H), torch.float32),   # fp32 [text | image] attention rows
+    }
+
+    def _lazy_buffer(self, name: str) -> torch.Tensor:
+        ws = self._ws_cache[self._ws_key]
+        t = ws.get(name)
+        if t is None:
+            L_img, T, C, B = self._ws_key[:4]
+            shape, dtype = self._LAZY_BUFFERS[name](B * (C + T + L_img), B, T, L_img, self.params.hidden_size)
+            t = ws[name] = torch.zeros(shape, device=self.device, dtype=dtype)
+        return t
+
+    QPRE = property(lambda self: self._lazy_buffer("QPRE"))
+    XML = property(lambda self: self._lazy_buffer("XML"))
+    QD = property(lambda self: self._lazy_buffer("QD"))
+    ATTI32 = property(lambda self: self._lazy_buffer("ATTI32"))
+
+    def clear_workspaces(self) -> None:
+        """Drop every cached activation set (up to WS_CACHE_ENTRIES sets stay resident between calls: ~1.6 GB per work
+        item at 1024 x 1024 with the capture buffers, 8 GB for a 5-item set); the next forward allocates afresh."""
+        for ws in self._ws_cache.values():
+            for k in ws:
+                self.__dict__.pop(k, None)
+        self._ws_cache.clear()
+        self._ws_key = None
+        self._rope_key = None
+
+    def workspace_bytes(self) -> int:
+        """Bytes of HBM the cached activation sets hold right now."""
+        return sum(t.numel() * t.element_size() for ws in self._ws_cache.values() for t in ws.values()
+                   if isinstance(t, torch.Tensor))
 
     def _alloc_workspace(self, L_img: int, T: int, C: int, B: int) -> dict:
         p, dev = self.params, self.device
@@ -329,16 +369,8 @@ class HipFluxDiT:
             ATT=torch.zeros(n, H, **bf),
             HID=torch.zeros(n, MLP, **bf),
             CAT=torch.zeros(B * (T + L_img), H + MLP, **bf),
-            # post-QKNorm, pre-RoPE q of the captured layers (cross-attention-space vectors) in fp32: their bf16 rounding
-            # alone was ~half of the cross-space heat-map error (tests/tools/error_budget.py)
-            QPRE=torch.zeros(n, H, **f32),
-            XML=torch.zeros(n, H, **bf),    # low plane of XM (captured layers): bf16(y - float(bf16(y)))
-            QD=torch.zeros(n, H, **f32),    # its q projection: the correction ops.qpre_finish adds before the norm
+            # (QPRE, XML, QD, ATTI32 -- the fp32 vectors of the captured layers -- are allocated on first use: _LAZY_BUFFERS)
             ATT32=torch.zeros(max(B * C, 1), H, **f32),  # fp32 copy of the concept attention rows
-            # ... and of each item's [text | image] attention rows in the layers whose maps are requested: the output-space
-            # logits are dot products over 3072 dims of two attention outputs, and the bf16 rounding of the image side
-            # was the largest remaining error of a single output-space map (the text rows ride along unused)
-            ATTI32=torch.zeros(B, T + L_img, H, **f32),
             TXT_IN=torch.zeros(B * (C + T), p.context_in_dim, **bf),
             PRED=torch.zeros(B * L_img, p.in_channels, **bf),
             PRED32=torch.zeros(B * L_img, p.in_channels, **f32),
@@ -587,7 +619,7 @@ class HipFluxDiT:
     def _f32_image_vectors(self, capture: bool, heatmaps) -> bool:
         """The attention kernel writes an fp32 copy of the [text | image] output rows in captured layers when the maps
         are reduced on the device (fused heat-map path); A/B: CA_F32_IMAGE_VECTORS=0."""
-        return bool(capture and heatmaps is not None and self.f32_image_vectors and self.precision != "fp8")
+        return bool(capture and heatmaps is not None and self.f32_image_vectors)
 
     def _ones_gate(self, n: int) -> torch.Tensor:
         g = getattr(self, "_ones_gate_vec", None)
@@ -618,12 +650,18 @@ class HipFluxDiT:
         im, tm = b + "img_mod.lin", b + "txt_mod.lin"
         capture = return_vectors or (heatmaps is not None and any(i in h.layer_indices for h in heatmaps))
         fp8 = self.precision == "fp8" and i not in self.keep_bf16_layers
+        # fp8 mode: the qkv projection of a layer whose maps are requested stays bf16 (round 4).  Its q / k / v ARE the
+        # vectors of that layer's maps, and e4m3's 3 mantissa bits on their GEMM operands cost a map 2-4e-2 against the
+        # fp32 oracle (tests/test_full_depth_gpu.py::test_fp8_forward_full_size_vs_fp32_oracle); proj and the MLP reach a
+        # map only through the residual stream.  25 % of a double block's projection FLOPs.
+        fp8_qkv = fp8 and not (capture and self.fp8_bf16_qkv_when_captured)
         if fp8:
             XM8, XMS, ATT8, ATTS, HID8, HIDS = self.XM8, self.XMS, self.ATT8, self.ATTS, self.HID8, self.HIDS
             xm_out = dict(out=XM8, out_scale=XMS)
         else:
             XM8 = XMS = ATT8 = ATTS = HID8 = HIDS = None
             xm_out = dict(out=XM)
+        xm_out_qkv = xm_out if fp8_qkv else dict(out=XM)
 
         def rows(t, lo, hi):
             return None if t is None else t[lo:hi]
@@ -638,8 +676,8 @@ class HipFluxDiT:
         gs = 0 if B == 1 else self._mod_cur.stride(0)   # floats between consecutive items' gate vectors
         G = self._gemm
         # K4: LayerNorm + (1+scale)*x+shift, per row range and item (:88-89,94-95,100-101)
-        split = capture and not fp8 and self.split_q_capture and self.residual_dtype == torch.float32 and C > 0
-        ops.ln_modulate(X, segments=[sg for sg in segs(0, 1) if sg[0] > 0], **xm_out,
+        split = capture and not fp8_qkv and self.split_q_capture and self.residual_dtype == torch.float32 and C > 0
+        ops.ln_modulate(X, segments=[sg for sg in segs(0, 1) if sg[0] > 0], **xm_out_qkv,
                         **({"out_lo": self.XML} if split else {}))
         # K5+K6+K7: qkv projections (image stream + [concept|text] stream in one grouped launch) with
         # QK-RMSNorm and RoPE fused into the epilogue; pre-RoPE q kept for the cross-attention maps
@@ -651,13 +689,13 @@ class HipFluxDiT:
             ops.gemm([ops.Gemm(self.XML[oI:], W[b + "img_attn.qkv.weight"][:H], None, self.QD[oI:]),
                       ops.Gemm(self.XML[:oT], W[b + "txt_attn.qkv.weight"][:H], None, self.QD[:oT])],
                      L.TILE_PP_256x256 if B * Li >= 4096 else L.TILE_AUTO)
-        self._launch_gemm([G(fp8, XM[oI:], rows(XM8, oI, n), rows(XMS, oI, n), b + "img_attn.qkv.weight",
+        self._launch_gemm([G(fp8_qkv, XM[oI:], rows(XM8, oI, n), rows(XMS, oI, n), b + "img_attn.qkv.weight",
                              W.tensors.get(b + "img_attn.qkv.bias"), QKV[oI:],
                              L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
                              norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[oI:],
                              q_prerope=None if qpre is None else qpre[oI:], q_out_scale=self._q_out_scale(),
                              qpre_raw=split, qk_f16=qk16),
-                           G(fp8, XM[:oI], rows(XM8, 0, oI), rows(XMS, 0, oI), b + "txt_attn.qkv.weight",
+                           G(fp8_qkv, XM[:oI], rows(XM8, 0, oI), rows(XMS, 0, oI), b + "txt_attn.qkv.weight",
                              W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:oI],
                              L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
                              norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:oI],

@@ -444,6 +444,36 @@ def test_split_q_capture_chain_matches_fp32_projection():
                      nq.float().cpu()).reshape(M, H)
     e_split, e_one = (qraw.cpu() - ref).abs().max().item(), (q1.cpu() - ref).abs().max().item()
     assert e_split < 2e-4 and e_split < 0.15 * e_one, (e_split, e_one)
+    # round 4: the same call also writes the ATTENTION's q (rotated, scaled, half or bf16) from that vector
+    rope_t = torch.randn(M, 64, 2, device=DEV)
+    rope_t = (rope_t / rope_t.norm(dim=-1, keepdim=True)).contiguous()
+    for f16 in (True, False):
+        qraw2 = torch.zeros(M, H, device=DEV)
+        outq = torch.zeros(M, 3 * H, device=DEV, dtype=torch.bfloat16)
+        ops.gemm([ops.Gemm(hi, w, b, outq, L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=nq, norm_k=nk, rope=rope_t,
+                           q_prerope=qraw2, qpre_raw=True, q_out_scale=SL2, qk_f16=f16)])
+        epi_q = outq[:, :H].clone()
+        kv_before = outq[:, H:].clone()
+        # without the low-plane correction the result is the epilogue's own q (same expressions; the row sums are
+        # reduced in another order, so an element may differ by one ulp of its storage type)
+        x0 = qraw2.clone()
+        ops.qpre_finish(x0, None, nq, nh, rope=rope_t, q_out=outq[:, :H], q_out_scale=SL2, q_f16=f16)
+        view = (lambda t_: t_.contiguous().view(torch.float16).float()) if f16 else (lambda t_: t_.float())
+        a_, b_ = view(outq[:, :H]), view(epi_q)
+        assert (a_ - b_).abs().max() <= (2.0 ** -10 if f16 else 2.0 ** -7) * b_.abs().max()
+        assert (a_ != b_).float().mean() < 0.02
+        assert torch.equal(outq[:, H:], kv_before)                          # k and v are not touched
+        # with it: the fp32 reference of the unrounded projection, rotated and scaled
+        ops.qpre_finish(qraw2, d, nq, nh, rope=rope_t, q_out=outq[:, :H], q_out_scale=SL2, q_f16=f16)
+        cs, sn = rope_t[..., 0].cpu()[:, None, :], rope_t[..., 1].cpu()[:, None, :]
+        r3 = ref.view(M, nh, 128)
+        re, ro = r3[..., 0::2], r3[..., 1::2]
+        want = torch.stack((cs * re - sn * ro, sn * re + cs * ro), -1).reshape(M, H) * SL2
+        got = view(outq[:, :H]).cpu()
+        assert (got - want).abs().max() < (5e-4 if f16 else 4e-3) * want.abs().max() + 5e-5, (f16, (got - want).abs().max())   # half an ulp of the storage type + the projection's own 2e-4
+        assert torch.equal(qraw2, qraw)                                     # the cross-space vector is the same as before
+    with pytest.raises(ValueError):
+        ops.qpre_finish(qraw, d, nq, nh, rope=rope_t[:5].contiguous(), q_out=outq[:, :H])
 
 
 def test_heatmap_logits_fp32_image_vectors():

@@ -218,6 +218,40 @@ def test_odd_sizes_end_to_end_vs_oracle(size, n_txt, C):
     assert (cm.cpu() - cm_o).abs().max() < 2e-2
 
 
+def test_reference_shaped_bf16_latent_loop_stays_exercised():
+    """CA_FP32_LATENT=0 (HipFluxDiT.fp32_latent = False): the Euler state is a bf16 tensor re-rounded after every step
+    and the prediction is bf16 -- the reference's own loop, flux/sampling.py:141 -- next to the default fp32 state.  Both
+    against the fp32 oracle; the default is at least as close, and the two latents differ by about 2^-9 per step, which
+    is what a caller comparing returned latents with a bf16 reference run will see."""
+    from conceptattention_amd.weights import synthetic_inputs, synthetic_state_dict
+    p = tiny_params()
+    sd = {k: v.bfloat16().float() for k, v in synthetic_state_dict(p, seed=4).items()}
+    inp = {k: (v.bfloat16().float() if v.is_floating_point() else v)
+           for k, v in synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=3, seed=6).items()}
+    pl = ConceptAttentionFluxPipeline("flux-schnell", device=DEV, weights=sd, params=p, n_text_tokens=8)
+    args = (inp["latent"].to(DEV), inp["txt"].to(DEV), inp["vec"].to(DEV), inp["concepts"].to(DEV))
+    kw = dict(layer_indices=[0, 1], num_inference_steps=4)
+    assert pl.model.fp32_latent is True
+    img32, hm32, _ = pl.generate_on_device(*args, **kw)
+    pl.model.fp32_latent = False
+    try:
+        img16, hm16, _ = pl.generate_on_device(*args, **kw)
+    finally:
+        pl.model.fp32_latent = True
+    assert img32.dtype == torch.bfloat16 and img16.dtype == torch.bfloat16      # what generate returns is bf16 either way
+    ts = O.get_schedule(4, 256, shift=False)
+    img_o, d = O.denoise(sd, p, O.patchify(inp["latent"]), inp["img_ids"], inp["txt"], inp["txt_ids"], inp["vec"],
+                         ts, 0.0, inp["concepts"], inp["concept_ids"], inp["concept_vec"])
+    hm_o = O.compute_heatmaps(d["output_space_image_vectors"], d["output_space_concept_vectors"], [0, 1], list(range(4)))
+    e32 = (img32.float().cpu() - img_o).pow(2).mean().sqrt().item()
+    e16 = (img16.float().cpu() - img_o).pow(2).mean().sqrt().item()
+    scale = img_o.pow(2).mean().sqrt().item()
+    assert e16 < 0.02 * scale and e32 <= e16 * 1.05, (e32, e16, scale)
+    assert (hm16.cpu() - hm_o).abs().max() < 5e-3 and (hm32.cpu() - hm_o).abs().max() < 5e-3
+    diff = (img32.float() - img16.float()).abs().max().item()
+    assert 0 < diff < 8 * 2.0 ** -9 * img_o.abs().max().item(), diff
+
+
 def test_encode_many_equals_one_by_one(pipe):
     """Image batches on two streams (configs[3] shape of work) give the maps of encode_image item by item."""
     from conceptattention_amd.weights import synthetic_inputs

@@ -482,3 +482,32 @@ def test_bf16_timesteps_switch_reproduces_the_reference_embedding(golden):
         mods[sw] = m._mod_steps.clone()
     assert not torch.equal(mods[False][0], mods[True][0])
     assert (mods[False][1] - mods[True][1]).abs().max() < 2e-2 * mods[False][1].abs().max()  # only the bf16 cast of the embedding
+
+
+def test_capture_buffers_are_lazy_and_workspaces_can_be_cleared():
+    """The fp32 capture buffers (QPRE, XML, QD, ATTI32: ~0.6 GB per work item at 1024 x 1024) exist only once a forward
+    asked for maps, and clear_workspaces() drops every cached activation set."""
+    from conceptattention_amd.weights import synthetic_inputs, synthetic_state_dict
+    p = tiny_params()
+    sd = {k: v.bfloat16().float() for k, v in synthetic_state_dict(p, seed=1).items()}
+    pl = ConceptAttentionFluxPipeline("flux-schnell", device=DEV, weights=sd, params=p, n_text_tokens=8)
+    m = pl.model
+    inp = synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=2, seed=2, dtype=torch.bfloat16)
+    from conceptattention_amd import sampling as S
+    con, con_ids, con_vec = S.concept_inputs(inp["concepts"].to(DEV), inp["vec"].to(DEV))
+    prep = S.prepare_from_embeddings(inp["latent"].to(DEV), inp["txt"].to(DEV), inp["vec"].to(DEV))
+    kw = dict(img=prep["img"], img_ids=prep["img_ids"], txt=prep["txt"], txt_ids=prep["txt_ids"], concepts=con,
+              concept_ids=con_ids, concept_vec=con_vec, y=prep["vec"], timesteps=torch.ones(1, device=DEV),
+              guidance=torch.zeros(1, device=DEV))
+    m(**kw, return_vectors=False)                       # no maps asked for
+    ws = m._ws_cache[m._ws_key]
+    assert not any(k in ws for k in ("QPRE", "XML", "QD", "ATTI32"))
+    before = m.workspace_bytes()
+    pred, d = m(**kw)                                   # the reference's call: all vectors returned
+    assert "QPRE" in ws and m.workspace_bytes() > before
+    assert d["cross_attention_image_vectors"].shape[0] == p.depth
+    m.clear_workspaces()
+    assert m.workspace_bytes() == 0 and m._ws_key is None
+    pred2, d2 = m(**kw)                                 # allocates afresh, same bits
+    assert torch.equal(pred, pred2)
+    assert torch.equal(d["output_space_image_vectors"], d2["output_space_image_vectors"])
