@@ -50,9 +50,11 @@ SINGLE_CROSS_SAME_INPUT_BOUND = 6.3e-4   # step 0 / encode path (the oracle's ow
 ENCODE_FINAL_OUT_BOUND = 3.3e-4   # one forward, mean of 4 layers: 2.2e-4 (round 3: 6.9e-4)
 ENCODE_FINAL_CROSS_BOUND = 2.5e-4 # 1.6e-4
 # fp8 mode (opt-in, never the headline) against the fp32 oracle; bounds to be read next to the measured values
-FP8_OUT_VS_ORACLE_BOUND = 6e-2
-FP8_CROSS_VS_ORACLE_BOUND = 0.12
-FP8_ARGMAX_VS_ORACLE_BOUND = 0.90
+# (round 4, with the qkv projection of the captured layers kept in bf16: output space <= 3.1e-3, cross space <= 8.6e-3,
+# arg-max concept agrees on >= 99.7 % of the patches; with every projection in e4m3: 4.0e-2 / 9.5e-2 / 95.3 %)
+FP8_OUT_VS_ORACLE_BOUND = 4.6e-3
+FP8_CROSS_VS_ORACLE_BOUND = 1.3e-2
+FP8_ARGMAX_VS_ORACLE_BOUND = 0.99
 
 
 def bf_inputs(p, size, T, C):
@@ -459,4 +461,5 @@ def test_fp8_layer_noise_sweep_full_size_vs_bf16(pipe):
                            "argmax_agree": agree}
     print("fp8 sweep: out", e_out.max(), "cross", e_cross.max(), "argmax agree", agree)
     assert torch.isfinite(f_out).all() and abs(f_out.sum(2).mean().item() - 1) < 1e-4
-    assert e_out.max() < 6e-2 and e_cross.max() < 0.12 and agree > 0.93
+    # (round 4: 2.5e-3 / 7.4e-3 / 99.8 % -- the qkv projection of a captured layer stays bf16; round 3: 3.1e-2 / 8.4e-2 / 96.6 %)
+    assert e_out.max() < 3.8e-3 and e_cross.max() < 1.2e-2 and agree > 0.99
