@@ -43,6 +43,7 @@ def audit_attn4(asm_path: str) -> None:
             bad.append(line.strip())
     bad += audit_sgpr_hazards(text)
     bad += audit_mfma_result_hazards(text)
+    bad += audit_asm_statements(text)
     # (every kernel of the unit: the bf16 and the half-precision-q/k instantiation)
     spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s*(\d+)", text)]
     scratch = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text)]
@@ -247,6 +248,40 @@ def audit_mfma_result_hazards(text: str) -> list:
             continue
         if prev_marked and op.startswith(("v_", "ds_", "buffer_", "global_", "scratch_", "flat_")):
             between.append(raw)
+    return sorted(set(bad))
+
+
+# the asm statements ca_attn4.hip is made of, outside the generated stream (which is marked `; a4s` per statement): what
+# each helper emits, instruction by instruction.  The hazard rules above were worked out for these shapes; a statement
+# with an MFMA, an LDS or a memory instruction that is none of them is new code nobody has audited.
+KNOWN_ASM_STATEMENTS = {
+    ("v_mfma_f32_32x32x16_bf16",): "one MFMA of the plain K Q^T / P V helpers",
+    ("v_mfma_f32_32x32x16_f16",): "the same, half-precision q / k",
+    ("ds_read_b128",): "a K fragment read of the plain helpers / the loop's preload",
+    ("ds_read_b64_tr_b16",): "a V fragment read of the plain P V helper",
+    ("s_mov_b32", "s_mov_b32", "s_nop", "global_load_lds_dwordx4", "s_mov_b32"): "ca_glds16_asm: M0 saved, one LDS-DMA piece, M0 restored",
+    ("s_mov_b32", "s_nop", "buffer_load_dwordx4"): "stage_pieces: one LDS-DMA piece through a buffer descriptor",
+}
+
+
+def audit_asm_statements(text: str) -> list:
+    """Every asm statement that contains an MFMA, an LDS or a memory instruction is either part of the generated stream
+    (marked) or one of KNOWN_ASM_STATEMENTS; anything else fails the build until it has been looked at and listed."""
+    bad, cur = [], None
+    for line in text.split("\n"):
+        if "#ASMSTART" in line:
+            cur = []
+            continue
+        if "#ASMEND" in line:
+            if cur is not None and not any("; a4s" in l for l in cur):
+                ops = tuple(l.split(";")[0].split()[0] for l in cur if l.split(";")[0].strip())
+                hot = any(o.startswith(("v_mfma", "v_smfmac", "buffer_", "global_", "flat_", "scratch_", "ds_")) for o in ops)
+                if hot and ops not in KNOWN_ASM_STATEMENTS:
+                    bad.append("unclassified asm statement: " + " ; ".join(ops))
+            cur = None
+            continue
+        if cur is not None:
+            cur.append(line.strip())
     return sorted(set(bad))
 
 

@@ -146,3 +146,17 @@ def test_shipped_stream_is_marked_for_the_audit():
     text = open(INC).read()
     sched = text[text.index("#ifdef CA_A4_SCHEDULE"):]
     assert sched.count("; a4s") == 3 * 128   # two statements per MFMA slot, three iteration variants
+
+
+def test_build_audit_classifies_every_hot_asm_statement():
+    """Outside the generated stream an asm statement with an MFMA / LDS / memory instruction must be one of the known
+    helper shapes; a new one fails the build until it has been looked at (housekeeping)."""
+    build = _load(os.path.join(ROOT, "conceptattention_amd", "csrc", "build.py"), "ca_build")
+    known = ("\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 v[0:15], a[0:3], a[4:7], 0\n\t;;#ASMEND\n"
+             "\t;;#ASMSTART\n\ts_mov_b32 m0, s3\n\ts_nop 4\n\tbuffer_load_dwordx4 v1, s[4:7], s9 offen lds\n\t;;#ASMEND\n"
+             "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\t;;#ASMEND\n")
+    assert build.audit_asm_statements(known) == []
+    marked = "\t;;#ASMSTART\n\tv_exp_f32 v1, v1 ; a4s\n\tds_write_b32 v2, v1\n\t;;#ASMEND\n"
+    assert build.audit_asm_statements(marked) == []          # the generated stream has its own rules
+    new = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 v[0:15], a[0:3], a[4:7], 0\n\tds_read_b128 a[0:3], v9\n\t;;#ASMEND\n"
+    assert any("unclassified" in b for b in build.audit_asm_statements(new))
