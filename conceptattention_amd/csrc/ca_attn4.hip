@@ -123,9 +123,18 @@ int ca_attn4_launch(const AttnLaunch &L, int total, bool qk_f16, hipStream_t str
     }
     attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
+  // more units than CUs: one workgroup per CU walks them (no workgroup dispatch between units; CA_ATTN_PERSIST=0: one
+  // workgroup per unit, round 3's launch)
+  static const bool persist = !(getenv("CA_ATTN_PERSIST") && atoi(getenv("CA_ATTN_PERSIST")) == 0);
+  int n_cu = 0, dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
+  AttnLaunch LL = L;
+  LL.total_units = total;
+  const int grid = (persist && n_cu > 0 && n_cu % 8 == 0 && total > n_cu) ? n_cu : total;
   if (qk_f16)
-    hipLaunchKernelGGL(ca_attn4_qk16_kernel, dim3(total), dim3(256), a4::LDS_BYTES, stream, L);
+    hipLaunchKernelGGL(ca_attn4_qk16_kernel, dim3(grid), dim3(256), a4::LDS_BYTES, stream, LL);
   else
-    hipLaunchKernelGGL(ca_attn4_kernel, dim3(total), dim3(256), a4::LDS_BYTES, stream, L);
+    hipLaunchKernelGGL(ca_attn4_kernel, dim3(grid), dim3(256), a4::LDS_BYTES, stream, LL);
   return CA_OK;
 }

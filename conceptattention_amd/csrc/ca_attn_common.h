@@ -10,6 +10,7 @@ struct AttnLaunch {
   int32_t n_problems;
   int32_t num_heads;
   float scale_log2;   // softmax scale * log2(e)
+  int32_t total_units;   // ca_attn4_kernel: workgroup-sized units of the launch (= its grid unless the walk is persistent)
   int32_t flags;      // bit 0: ca_attn4_kernel without its in-place re-reference (CA_ATTN_REREF=0), bit 1: with round 3's
                       // row-sum limit of 2^60 instead of 2^100 (CA_ATTN_LIMIT60=1); both A/B aids of tools/attn_peaky.py
 };

@@ -219,15 +219,15 @@ class HipFluxDiT:
         # untouched, so the image does not depend on which layers are captured.  "0" = one rounding more (A/B aid).
         self.split_q_capture = os.environ.get("CA_SPLIT_Q_CAPTURE", "1") != "0"
         # The rotated q and k of the attention as IEEE half instead of bf16 (ca_gemm_problem.qk_f16 ->
-        # ca_attn_fwd_qk16): their bf16 rounding is what bounds a single output-space heat map (round 4,
-        # tests/tools/error_budget.py --out-space2: 9e-4 -> 2.5e-4 per map with 11-bit q / k; v and the probabilities
-        # do not matter), the f16 MFMA has the bf16 one's rate, and behind an RMS norm the values sit far inside
-        # fp16's range.  "all" (default): every block, so that the image does not depend on which layers are
-        # captured; "captured": only the layers whose maps are requested; "0": bf16 as the reference (A/B aid).
-        # Needs the pre-scaled-q kernel (CA_ATTN_PRESCALE / CA_ATTN_KERNEL=8 switch it off).
-        self.split_q_attention = os.environ.get("CA_SPLIT_Q_ATTENTION", "1") != "0"
-        self.fp8_bf16_qkv_when_captured = os.environ.get("CA_FP8_QKV_BF16_CAPTURED", "1") != "0"
-        self.qk_f16 = os.environ.get("CA_QK_F16", "all")
+        # ca_attn_fwd_qk16): their bf16 rounding is one of the two things that bound a single output-space heat map
+        # (round 4, tests/tools/error_budget.py --out-space2: 9e-4 -> 2.5e-4 per map with 11-bit q / k; v and the
+        # probabilities do not matter), and behind an RMS norm the values sit far inside fp16's range.  "captured"
+        # (default): the layers whose maps are requested -- where the attention's q is special anyway (split_q_attention
+        # below); the chip clocks the f16 MFMA 1.6 % lower than the bf16 one, and with every block in half precision
+        # ("all") the maps are no closer to the oracle (profiles/r04_full_depth_parity*.json: 5.6e-4 / 9.6e-4 worst single
+        # map against 5.7e-4 / 8.4e-4) at -0.6 % heat maps/s.  "0": bf16 everywhere, as the reference (A/B aid).
+        # Needs the pre-scaled-q kernel (CA_ATTN_PRESCALE=0 / CA_ATTN_KERNEL=8 switch it off).
+        self.qk_f16 = os.environ.get("CA_QK_F16", "captured")
         if self.qk_f16 not in ("all", "captured", "0"):
             raise ValueError("CA_QK_F16 must be all, captured or 0")
         if not self.prescale_q or os.environ.get("CA_ATTN_KERNEL") == "8":
