@@ -228,6 +228,11 @@ class HipFluxDiT:
         # map against 5.7e-4 / 8.4e-4) at -0.6 % heat maps/s.  "0": bf16 everywhere, as the reference (A/B aid).
         # Needs the pre-scaled-q kernel (CA_ATTN_PRESCALE=0 / CA_ATTN_KERNEL=8 switch it off).
         self.qk_f16 = os.environ.get("CA_QK_F16", "captured")
+        # the ATTENTION's q of the captured layers' image / concept rows from the unrounded LayerNorm output as well
+        # (ops.qpre_finish writes it over the epilogue's; _double_block); "0" = round 3's q (A/B aid)
+        self.split_q_attention = os.environ.get("CA_SPLIT_Q_ATTENTION", "1") != "0"
+        # fp8 mode: the qkv projection of a layer whose maps are requested stays bf16 (_double_block)
+        self.fp8_bf16_qkv_when_captured = os.environ.get("CA_FP8_QKV_BF16_CAPTURED", "1") != "0"
         if self.qk_f16 not in ("all", "captured", "0"):
             raise ValueError("CA_QK_F16 must be all, captured or 0")
         if not self.prescale_q or os.environ.get("CA_ATTN_KERNEL") == "8":
