@@ -119,3 +119,23 @@ def test_row_geometry_of_a_batched_forward():
     assert (g.oT, g.oI, g.n) == (20, 1300, 21780)
     # the single blocks' [text | image] rows of five items are exactly 85 row tiles of 256 (1020 tiles at N = 3072)
     assert (g.n - g.oT) % 256 == 0 and (g.n - g.oT) // 256 == 85
+
+
+def test_every_attribute_the_model_reads_is_assigned_somewhere():
+    import os
+    """HipFluxDiT cannot be constructed without a GPU, so a deleted `self.x = ...` line in its constructor would only
+    show on the GPU box (it did once, round 4).  Static check: every `self.<name>` the class reads is assigned, defined
+    as a method / property, or a workspace buffer."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conceptattention_amd",
+                            "flux_dit.py")).read()
+    cls = src[src.index("class HipFluxDiT"):]
+    used = set(re.findall(r"self\.([A-Za-z_][A-Za-z_0-9]*)\b", cls))
+    assigned = (set(re.findall(r"self\.([A-Za-z_][A-Za-z_0-9]*)\s*=[^=]", cls)) |
+                set(re.findall(r"def ([A-Za-z_][A-Za-z_0-9]*)\(", cls)) |
+                set(re.findall(r"^    ([A-Za-z_][A-Za-z_0-9]*) = ", cls, re.M)) |
+                set(re.findall(r"^\s+([A-Z][A-Z0-9_]*)=torch\.", cls, re.M)) |          # _alloc_workspace's buffers
+                set(re.findall(r'"([A-Z][A-Z0-9_]*)":\s*lambda', cls)) |                 # _LAZY_BUFFERS
+                set(re.findall(r"([A-Z][A-Z0-9_]*)=torch\.zeros", cls)))
+    missing = sorted(used - assigned - {"__dict__"})
+    assert missing == [], missing
