@@ -56,10 +56,10 @@ def on_box(rnd: int, head: str):
     counts = json.loads([l for l in trace_log.splitlines() if l.startswith("{")][-1])["launch_counts"]
     import csv as _csv
     calls = {}
-    for r in _csv.DictReader(lines):
-        for key, pat in (("gemm_tile_5", "ca_gemm_pp_kernel<2, 2, false>"), ("attn", "ca_attn4_kernel")):
+    for r in _csv.DictReader(lines):   # (attention: the bf16 and the half-precision-q/k instantiation together)
+        for key, pat in (("gemm_tile_5", "ca_gemm_pp_kernel<2, 2, false>"), ("attn", "ca_attn4_")):
             if pat in r["Name"]:
-                calls[key] = int(r["Calls"])
+                calls[key] = calls.get(key, 0) + int(r["Calls"])
     mix = dict(LAUNCH_MIX, calls_per_group=counts, calls_in_trace=calls)
     for key, n in calls.items():
         if n != 2 * counts.get(key, -1):   # bench.py then refuses the traffic file (only_batched_launches False)
