@@ -660,6 +660,15 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
       sa[mi] = P.a_scale[min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1)];
+    // (two passes, row scale then column scale: with the product sa[mi] * sw[r] written out hipcc builds the whole
+    // 8 x 16 table of products next to the 128 accumulators and spills 44 registers around it)
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NT_; ++nj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][nj][r] *= sa[mi];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nj = 0; nj < NT_; ++nj) {
       const int n = nj < NL ? n0 + wn * 16 * NL + 4 * NL * (lane >> 4) + 4 * nj
@@ -668,7 +677,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[mi][nj][r] *= sa[mi] * sw[r];
+        for (int r = 0; r < 4; ++r) acc[mi][nj][r] *= sw[r];
     }
     // keep the epilogue's loads (bias, gates, residual rows) below this point: hoisted above the scaling they
     // overlap its temporaries with all 128 accumulators and spill
