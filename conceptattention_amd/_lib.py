@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# CA_LIB_PATH: another build of the same library (A/B and diagnostic builds under tools/ab_libs); still no fallback
+# CA_LIB_PATH: another build of the same library (A/B and diagnostic builds under tools/ab); still no fallback
 LIB_PATH = os.environ.get("CA_LIB_PATH") or os.path.join(_HERE, "libconceptattn.so")
 
 CA_VERSION = 124

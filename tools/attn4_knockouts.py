@@ -2,7 +2,7 @@
 stamped build (tools/stamp_attn4.py) of a stream generated with one ingredient removed (tools/gen_attn4_schedule.py,
 CA_A4_KO); the results of such builds are wrong by construction, only their stamps are read.
 
-    python tools/attn4_knockouts.py build     # here (no GPU): tools/ab_libs/ko_<variant>/libca.so
+    python tools/attn4_knockouts.py build     # here (no GPU): tools/ab/ko_<variant>/libca.so
     python tools/attn4_knockouts.py           # on the GPU box: one line per variant
 """
 import os
@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "conceptattention_amd", "csrc")
-AB = os.path.join(ROOT, "tools", "ab_libs")
+AB = os.path.join(ROOT, "tools", "ab")
 VARIANTS = ["none", "exp", "add", "exp,add", "cvt", "lds", "dma", "exp,add,cvt", "exp,add,cvt,lds,dma"]
 if os.environ.get("CA_A4_VARIANTS"):      # e.g. "none;order:valu_first;order:mem_first" (order:* = placement inside a gap)
     VARIANTS = os.environ["CA_A4_VARIANTS"].split(";")

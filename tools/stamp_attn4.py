@@ -1,7 +1,7 @@
 """Cycle shares of ca_attn4_kernel's tile loop (diagnostic build with -DCA_A4_STAMP, s_memtime around the three parts
 of an iteration: tile-base bookkeeping | the 64-MFMA instruction stream | drain + barrier).
 
-    python tools/stamp_attn4.py build     # here (no GPU): tools/ab_libs/libca_a4_stamp.so
+    python tools/stamp_attn4.py build     # here (no GPU): tools/ab/libca_a4_stamp.so
     python tools/stamp_attn4.py           # on the GPU box
 
 Read the SHARES, not the length: the stamps' own waits forbid overlaps the real kernel has (cdna_hip_programming.md 7)."""
@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "conceptattention_amd", "csrc")
-LIB = os.environ.get("CA_A4_STAMP_LIB") or os.path.join(ROOT, "tools", "ab_libs", "libca_a4_stamp.so")
+LIB = os.environ.get("CA_A4_STAMP_LIB") or os.path.join(ROOT, "tools", "ab", "libca_a4_stamp.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
