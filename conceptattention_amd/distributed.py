@@ -81,11 +81,11 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
-def collective_evidence(device) -> dict | None:
+def collective_evidence(device, force_collective: bool = False) -> dict | None:
     """What a reader of the bench line needs to believe that N ranks took part: the backend, how many ranks an
     all_reduce(sum) of 1 saw, and the device every rank ran on (all_gather of its index and its PCI bus id), so that
     a job whose ranks all sat on one GPU, or whose group is smaller than --gpus, shows in its own JSON."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)):
         return None
     world, backend = dist.get_world_size(), dist.get_backend()
     on = torch.device(device) if backend == "nccl" else torch.device("cpu")

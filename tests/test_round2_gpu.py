@@ -443,6 +443,8 @@ acc = torch.full((4, 64), 2.5, device="cuda:0")
 assert torch.equal(D.allreduce_sum_(acc.clone(), force_collective=True), acc)
 t = torch.tensor([1.25], dtype=torch.float64, device="cuda:0")
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
+ev = D.collective_evidence(torch.device("cuda:0"), force_collective=True)   # the record an N > 1 bench line carries
+assert ev["backend"].startswith("rccl") and ev["ranks_seen"] == 1 and ev["devices"] == [0] and ev["distinct_devices"] == 1, ev
 dist.barrier()
 torch.cuda.synchronize()
 dist.destroy_process_group()
