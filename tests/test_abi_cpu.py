@@ -96,6 +96,32 @@ def test_argument_rejection_needs_no_gpu(lib):
     assert lib.ca_gemv_bf16(None, 9, 0, None, None, None, 0, 0, 0, 0, 0, None) == -1
 
 
+def test_auto_tile_picks_the_256x256_ping_pong_tile_for_the_models_launches(lib):
+    """ca_gemm_auto_tile needs no GPU.  Round 4's trace of the one-item forward found proj and mlp.2 on 256x128 tiles
+    (two rounds of half-width tiles, 130 / 416 us against 62 / 222 us): the chooser had priced the thin-row launch of the
+    4 concept rows at 0.3 round although those rows fit into the CUs the 204 main tiles leave idle.  Pin the choice for
+    the grouped launches of the model at 1 and 5 items per forward."""
+    H = 3072
+
+    def tile(probs):
+        arr = (L.GemmProblem * len(probs))()
+        for i, (M, N, K, epi, n_split) in enumerate(probs):
+            arr[i].M, arr[i].N, arr[i].K, arr[i].epilogue, arr[i].n_split = M, N, K, epi, n_split
+        return lib.ca_gemm_auto_tile(arr, len(probs))
+    for B in (1, 5):
+        img, ctx, rows = B * 4096, B * 260, B * 4352
+        launches = {"qkv": [(img, 3 * H, H, L.EPI_QKV_NORM_ROPE, 3 * H), (ctx, 3 * H, H, L.EPI_QKV_NORM_ROPE, 3 * H)],
+                    "proj": [(img, H, H, L.EPI_GATE_RESIDUAL, 0), (ctx, H, H, L.EPI_GATE_RESIDUAL, 0)],
+                    "mlp.0": [(img, 4 * H, H, L.EPI_GELU_TANH, 0), (ctx, 4 * H, H, L.EPI_GELU_TANH, 0)],
+                    "mlp.2": [(img, H, 4 * H, L.EPI_GATE_RESIDUAL, 0), (ctx, H, 4 * H, L.EPI_GATE_RESIDUAL, 0)],
+                    "linear1": [(rows, 7 * H, H, L.EPI_QKV_NORM_ROPE, 3 * H)],
+                    "linear2": [(rows, H, 5 * H, L.EPI_GATE_RESIDUAL, 0)]}
+        for name, probs in launches.items():
+            assert tile(probs) == L.TILE_PP_256x256, (B, name, tile(probs))
+    # a narrow problem still gets a narrower tile (N = 128 does not divide by 256)
+    assert tile([(4096, 128, 3072, L.EPI_BIAS, 0)]) in (L.TILE_PP_256x128, L.TILE_256x64)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "_lib", None)
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
