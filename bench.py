@@ -285,6 +285,7 @@ def main():
     # costs a ~5 us pipeline drain around the launch (616 GEMM launches per call = 2.3 % of a call), so
     # the events are recorded during the LAST timed step only; the other timed steps run unperturbed.
     records = []
+    EPI_NAMES = {0: "bias", 1: "gelu", 2: "gate*x+residual", 3: "split(bias|gelu)", 4: "qk-norm+rope(+gelu)"}
 
     def has_main_tiles(arr):
         """Does this call launch the tile kernel at all?  A problem of <= 128 rows (the modulation GEMM's 40 vectors) is
@@ -299,7 +300,9 @@ def main():
         s.record()
         launch()
         e.record()
-        records.append((tile, fl, s, e))
+        shape = (f"M{'+'.join(str(arr[i].M) for i in range(len(arr)))} N{arr[0].N} K{arr[0].K} "
+                 f"{EPI_NAMES.get(arr[0].epilogue, arr[0].epilogue)}")
+        records.append((tile, fl, s, e, shape))
 
     attn_records = []
 
@@ -450,12 +453,21 @@ def main():
         if records:
             torch.cuda.synchronize()
             by_tile = {}
-            for tile, fl, s, e in records:
+            by_shape = {}
+            for tile, fl, s, e, shape in records:
                 d = by_tile.setdefault(tile, [0.0, 0.0, 0])
                 d[0] += fl
                 d[1] += s.elapsed_time(e) * 1e-3
                 d[2] += 1
+                b = by_shape.setdefault((tile, shape), [0.0, 0.0, 0])
+                b[0] += fl
+                b[1] += s.elapsed_time(e) * 1e-3
+                b[2] += 1
             tile, (fl, sec, n) = max(by_tile.items(), key=lambda kv: kv[1][1])
+            # the same figure per launch shape of the dominant kernel (in situ: the model's own operands and epilogues)
+            shapes = {sh: {"launches": b[2], "avg_launch_us": b[1] / b[2] * 1e6, "achieved": b[0] / b[1] / 1e12,
+                           "share_of_kernel_time": b[1] / sec}
+                      for (tl, sh), b in sorted(by_shape.items(), key=lambda kv: -kv[1][1]) if tl == tile and b[1] > 0.005 * sec}
             names = {1: "ca_gemm_kernel<8,4> (256x256x64)", 2: "ca_gemm_kernel<8,3> (256x192x64)",
                      3: "ca_gemm_kernel<8,2> (256x128x64)", 4: "ca_gemm_kernel<8,1> (256x64x64)",
                      5: "ca_gemm_pp_kernel<2,2> (256x256x64 ping-pong)", 6: "ca_gemm_pp_kernel<1,1> (256x128x64 ping-pong)",
@@ -472,7 +484,8 @@ def main():
                         timed_on=f"last group of {n_last} work items of rank 0 (one forward per diffusion step)",
                         launch_is="one ca_gemm_bf16 call: the ping-pong launch plus, for a thin last row tile, "
                                   "its thin-row launch (ca_gemm_thin_kernel); rocprofv3 lists the two kernels separately",
-                        share_of_that_group=sec / (elapsed * n_last / max(len(timed_items), 1)))
+                        share_of_that_group=sec / (elapsed * n_last / max(len(timed_items), 1)),
+                        by_shape=shapes)
         else:
             roof.update(kernel="whole path", achieved=path_tflops)
         roof_attn = None

@@ -28,6 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
         d = os.path.dirname(lib_of(v))
         os.makedirs(d, exist_ok=True)
         shutil.copy(os.path.join(SRC, "ca_attn4.hip"), d)
+        shutil.copy(os.path.join(SRC, "ca_attn4_kernel.inc"), d)   # (it includes the schedule: must sit next to the variant)
         env = dict(os.environ, CA_A4_OUT=os.path.join(d, "ca_attn4_sched.inc"))
         env["CA_A4_ORDER" if v.startswith("order:") else "CA_A4_KO"] = "" if v == "none" else v.split(":")[-1]
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_attn4_schedule.py")], env=env,
