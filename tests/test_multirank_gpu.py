@@ -51,3 +51,8 @@ def test_two_ranks_equal_one_rank_bit_for_bit(tmp_path, workload, extra):
     assert np.array_equal(a, b), float(np.abs(a - b).max())
     assert not np.array_equal(a[0], a[1])          # the items differ: an order mix-up could not go unnoticed
     assert one["batched_equals_single"] is True and two["batched_equals_single"] is True
+    # the N > 1 line says which group ran it: here two gloo ranks that were both pinned to device 0 -- exactly what a
+    # reader of an 8-GPU line must be able to rule out ("distinct_devices")
+    ev = two["collective"]
+    assert "collective" not in one
+    assert ev["backend"] == "gloo" and ev["ranks_seen"] == 2 and ev["devices"] == [0, 0] and ev["distinct_devices"] == 1
