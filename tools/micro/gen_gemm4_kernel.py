@@ -21,6 +21,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 MFMA = "v_mfma_f32_16x16x32_bf16"
 KO = set(filter(None, os.environ.get("GEMM4_KO", "").split(",")))   # timing-only knock-outs: vmcnt, barrier, dma, lds
 OUTNAME = os.environ.get("GEMM4_OUT", "gemm4_kernel_probe.inc")
+# "bunched" (round 3): one barrier per K tile in the middle of step 1, the 16 DMA pieces and the 16 reads of the next tile
+# share the 32 slots behind it.  "spread" (round 4, after reading how hipBLASLt's hand-written 4-wave kernel does it --
+# profiles/r04_vendor_kernel_names.json): once a wave's step-1 fragments are in registers the WHOLE stage is dead (its
+# step-0 fragments were read a tile ago), so a barrier at the top of step 1 frees it and the 16 pieces of tile t+2 go out
+# one per four MFMAs over all 64 slots of step 1; a second barrier in the middle (vmcnt(8): the 8 pieces issued so far
+# may stay in flight) publishes tile t+1 for the 16 reads of its step 0.
+SCHED = os.environ.get("GEMM4_SCHED", "spread")
 
 
 def mfma(i, j):
@@ -49,23 +56,33 @@ def gen(st):
             n += 1
     # step 1: fragments in buffer 1
     L.append(f'    asm volatile("s_waitcnt lgkmcnt(0)" : {allf(1)} :: "memory");')
+    if SCHED == "spread" and "barrier" not in KO:
+        L.append('    asm volatile("s_barrier" ::: "memory");   // every wave holds its step-1 fragments: this stage is free')
     n = 0
     piece = 0
     for i in range(8):
         for j in range(8):
             m = mfma(i, j)
             if n == 32:
-                sync = [] if "vmcnt" in KO else ["s_waitcnt vmcnt(0)"]
+                if SCHED == "spread":
+                    sync = [] if "vmcnt" in KO else ["s_waitcnt vmcnt(8)"]
+                else:
+                    sync = [] if "vmcnt" in KO else ["s_waitcnt vmcnt(0)"]
                 sync += [] if "barrier" in KO else ["s_barrier"]
                 if sync:
                     L.append('    asm volatile("' + "\\n\\t".join(sync) + '" ::: "memory");')
-            if n >= 32 and n % 2 == 0 and "lds" not in KO:          # a fragment read of the next tile's step 0 (other stage) -> buffer 0
+            is_read = n >= 32 and n % 2 == 0 and "lds" not in KO
+            if SCHED == "spread":
+                is_dma = n % 4 == 1 and "dma" not in KO
+            else:
+                is_dma = n >= 32 and n % 2 == 1 and "dma" not in KO
+            if is_read:          # a fragment read of the next tile's step 0 (other stage) -> buffer 0
                 f = (n - 32) // 2
                 dst = f"FA[0][{f}]" if f < 8 else f"FW[0][{f - 8}]"
                 adr = f"aaddr[0][{f}]" if f < 8 else f"waddr[0][{f - 8}]"
                 L.append(f'    asm volatile("{m.format(w="1", a="2")}\\n\\tds_read_b128 %0, %3 offset:{nxt_off}" : "=&v"({dst}) : '
                          f'"v"(FW[1][{j}]), "v"(FA[1][{i}]), "v"({adr}) : "memory");')
-            elif n >= 32 and n % 2 == 1 and "dma" not in KO:                       # an LDS-DMA piece of tile t+2 into this stage: A pieces 0..7, W pieces 0..7
+            elif is_dma:                       # an LDS-DMA piece of tile t+2 into this stage: A pieces 0..7, W pieces 0..7
                 p = piece
                 piece += 1
                 isw = p >= 8
