@@ -231,13 +231,14 @@ def test_reference_shaped_bf16_latent_loop_stays_exercised():
     pl = ConceptAttentionFluxPipeline("flux-schnell", device=DEV, weights=sd, params=p, n_text_tokens=8)
     args = (inp["latent"].to(DEV), inp["txt"].to(DEV), inp["vec"].to(DEV), inp["concepts"].to(DEV))
     kw = dict(layer_indices=[0, 1], num_inference_steps=4)
-    assert pl.model.fp32_latent is True
+    default = pl.model.fp32_latent                     # True unless CA_FP32_LATENT=0 is set for the whole run
+    pl.model.fp32_latent = True
     img32, hm32, _ = pl.generate_on_device(*args, **kw)
     pl.model.fp32_latent = False
     try:
         img16, hm16, _ = pl.generate_on_device(*args, **kw)
     finally:
-        pl.model.fp32_latent = True
+        pl.model.fp32_latent = default
     assert img32.dtype == torch.bfloat16 and img16.dtype == torch.bfloat16      # what generate returns is bf16 either way
     ts = O.get_schedule(4, 256, shift=False)
     img_o, d = O.denoise(sd, p, O.patchify(inp["latent"]), inp["img_ids"], inp["txt"], inp["txt_ids"], inp["vec"],
