@@ -34,8 +34,8 @@ using namespace ca_attn_detail;
 // one compare looks at the wave's running sums, and a wave that finds one above 2^64 RE-REFERENCES in place
 // (rereference(): every row's reference moves up by the exponent of its sum, O / l / the pending probabilities are
 // scaled by the exact power of two; no key is visited twice).  What is left for the final check is a sum that
-// overflowed between two compares (a score more than ~60 octaves above an already large running sum, i.e. > 120
-// octaves above tile 0's maximum within three tiles; inf / NaN inputs): the
+// passed 2^100 or overflowed between two compares (a score more than ~36 octaves above a running sum that was just
+// short of 2^64, i.e. ~100 octaves above the row's current reference within three tiles; inf / NaN inputs): the
 // workgroup then recomputes its rows the classical way (running maximum, rescale per tile).
 // The two waves of a SIMD in ca_attn_kernel run in lockstep (same program, one barrier per tile): per tile the matrix
 // pipe idles while both exponentiate.  Here the single wave's own stream keeps it fed (2 265
