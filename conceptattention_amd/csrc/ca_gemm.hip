@@ -33,6 +33,8 @@ struct GemmLaunch {
   int32_t nt[CA_GEMM_MAX_PROBLEMS];
   int32_t persist_tiles;  // ping-pong kernel: 0 = one workgroup per tile; else total tiles, walked by a CU-sized grid
   int32_t persist_tiles_grid;  // host only: workgroups of the persistent grid (= CUs, a multiple of 8)
+  int32_t group_m;        // ping-pong kernel: row tiles per group of the tile order (the 32 concurrent tiles of an XCD are
+                          // a group_m x 32/group_m patch); chosen per launch shape by the host (pick_group_m)
   // ping-pong kernel, tile order: the tiles of a problem's LAST row tile go to the end of the walk when that row tile
   // is thin (few valid rows), all other ("main") tiles keep the XCD-patch order among themselves
   int32_t main_total;                        // main tiles of all problems
@@ -391,10 +393,11 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     prob = (lid >= L.ntiles_main[0]) ? 1 : 0;
     if (prob) lid -= L.ntiles_main[0];
     const int MT = L.mt_main[prob], NT = L.nt[prob];
-    const int grp = lid / (GROUP_M * NT);
-    const int first_m = grp * GROUP_M;
-    const int gm = min(GROUP_M, MT - first_m);
-    const int in_grp = lid - grp * GROUP_M * NT;
+    const int GM = L.group_m;
+    const int grp = lid / (GM * NT);
+    const int first_m = grp * GM;
+    const int gm = min(GM, MT - first_m);
+    const int in_grp = lid - grp * GM * NT;
     mtile = first_m + in_grp % gm;
     ntile = in_grp / gm;
   } else {  // thin tiles, after all main tiles: the last row tile of a problem, one tile per column block
@@ -1333,6 +1336,26 @@ int tile_n_of(int tile) {
   }
 }
 
+// Row tiles per group of the ping-pong kernel's tile order.  The 32 workgroups an XCD runs at a time work on 32
+// consecutive tiles of that order: a group_m x (32 / group_m) patch of the output, i.e. group_m A panels and 32 / group_m
+// W panels through the XCD's L2, and rows of 32 / group_m x 512 contiguous output bytes in the round's store burst.
+// It had been 8 everywhere (a square-ish patch: the fewest panels).  Round 4 measured the model's six grouped launches with
+// 1 .. 32 (tools/gemm_group_m.py, profiles/r04_gemm_group_m.txt): at 5 items per forward every launch is 2-4 % faster with
+// FEWER row tiles per group (wider rows of output per XCD and round), and which count is best depends on the number of
+// column tiles -- 12 (N = 3072: proj, mlp.2, linear2): 1;  36-48 (qkv, mlp.0): 4;  84 (linear1): 2-3.  With one item per
+// forward (17 row tiles) the choice matters less than 1 %, except that the N = 3072 launches prefer 2-4 to 1.
+// CA_GEMM_GROUP_M overrides (A/B aid).  The order of the tiles changes nothing about any tile's result.
+int pick_group_m(int nt, int mt) {
+  static const int env = [] {
+    const char *e = getenv("CA_GEMM_GROUP_M");
+    return e ? atoi(e) : 0;
+  }();
+  if (env > 0) return env;
+  if (nt <= 16) return mt >= 48 ? 1 : 4;
+  if (nt >= 64) return 3;
+  return 4;
+}
+
 // CU count of the current device (cached per device; a race only repeats the query); -1 if the query fails
 int ca_cu_count() {
   static std::atomic<int> cus[64];
@@ -1531,6 +1554,7 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
     const char *e = getenv("CA_GEMM_THIN_KERNEL");  // 0: thin rows stay 256-column tiles of the ping-pong walk (A/B aid)
     return e ? atoi(e) : 1;
   }();
+  L.group_m = pick_group_m(L.nt[0], L.mt[0]);
   const int n_cu = ca_cu_count();
   // Thin last row tiles (<= CA_GEMM_THIN_ROWS valid rows) under the bf16 256x256 tile normally get their own launch of
   // 32 x 128 tiles behind the main one (ca_gemm_thin_kernel).  But when the main tiles leave enough CUs idle in their
