@@ -33,6 +33,7 @@ struct GemmLaunch {
   int32_t nt[CA_GEMM_MAX_PROBLEMS];
   int32_t persist_tiles;  // ping-pong kernel: 0 = one workgroup per tile; else total tiles, walked by a CU-sized grid
   int32_t persist_tiles_grid;  // host only: workgroups of the persistent grid (= CUs, a multiple of 8)
+  int32_t xcd_interleave; // ping-pong kernel: the XCDs share each full round's 256 consecutive tiles (tile order below)
   int32_t group_m;        // ping-pong kernel: row tiles per group of the tile order (the 32 concurrent tiles of an XCD are
                           // a group_m x 32/group_m patch); chosen per launch shape by the host (pick_group_m)
   // ping-pong kernel, tile order: the tiles of a problem's LAST row tile go to the end of the walk when that row tile
@@ -388,8 +389,17 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
 
   int prob, mtile, ntile;
   if (bid < L.main_total) {
-    const int xcd = bid & 7, q8 = L.main_total >> 3, r8 = L.main_total & 7;
-    int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int xcd = bid & 7;
+    int lid;
+    if (L.xcd_interleave && bid < (L.main_total & ~255)) {
+      // the 8 XCDs share one run of 256 consecutive tiles per full round (XCD x: tiles 32 x .. 32 x + 31 of it); the
+      // partial last round keeps the XCD-contiguous split (any bijection does: its tiles are a few per XCD)
+      lid = (bid & ~255) + 32 * xcd + ((bid >> 3) & 31);
+    } else {
+      const int base = L.xcd_interleave ? (L.main_total & ~255) : 0, tot = L.main_total - base, b = bid - base;
+      const int q8 = tot >> 3, r8 = tot & 7;
+      lid = base + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    }
     prob = (lid >= L.ntiles_main[0]) ? 1 : 0;
     if (prob) lid -= L.ntiles_main[0];
     const int MT = L.mt_main[prob], NT = L.nt[prob];
@@ -1345,12 +1355,13 @@ int tile_n_of(int tile) {
 // column tiles -- 12 (N = 3072: proj, mlp.2, linear2): 1;  36-48 (qkv, mlp.0): 4;  84 (linear1): 2-3.  With one item per
 // forward (17 row tiles) the choice matters less than 1 %, except that the N = 3072 launches prefer 2-4 to 1.
 // CA_GEMM_GROUP_M overrides (A/B aid).  The order of the tiles changes nothing about any tile's result.
-int pick_group_m(int nt, int mt) {
+int pick_group_m(int nt, int mt, bool interleave) {
   static const int env = [] {
     const char *e = getenv("CA_GEMM_GROUP_M");
     return e ? atoi(e) : 0;
   }();
   if (env > 0) return env;
+  if (interleave) return nt <= 16 ? 4 : 6;   // (with the XCDs sharing each run of 256 tiles the choice is flat over 4 .. 8)
   if (nt <= 16) return mt >= 48 ? 1 : 4;
   if (nt >= 64) return 3;
   return 4;
@@ -1554,7 +1565,12 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
     const char *e = getenv("CA_GEMM_THIN_KERNEL");  // 0: thin rows stay 256-column tiles of the ping-pong walk (A/B aid)
     return e ? atoi(e) : 1;
   }();
-  L.group_m = pick_group_m(L.nt[0], L.mt[0]);
+  // the 8 XCDs share each run of 256 consecutive tiles of the order (XCD x: its tiles 32 x .. 32 x + 31) instead of
+  // owning one eighth of the order each: all of them stream the same group of A rows at a time (CA_GEMM_XCD_INTERLEAVE=0:
+  // rounds 1-3's contiguous ranges)
+  static const int xil = [] { const char *e = getenv("CA_GEMM_XCD_INTERLEAVE"); return e ? atoi(e) : 1; }();
+  L.xcd_interleave = xil;
+  L.group_m = pick_group_m(L.nt[0], L.mt[0], xil != 0);
   const int n_cu = ca_cu_count();
   // Thin last row tiles (<= CA_GEMM_THIN_ROWS valid rows) under the bf16 256x256 tile normally get their own launch of
   // 32 x 128 tiles behind the main one (ca_gemm_thin_kernel).  But when the main tiles leave enough CUs idle in their

@@ -39,7 +39,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--run":
     sys.exit(0)
 
 res = {}
-modes = ["auto", "1", "2", "3", "4", "6", "8"]
+modes = ["auto", "1", "2", "3", "4", "6", "8", "12", "16"]
 for g in modes:
     env = dict(os.environ)
     env.pop("CA_GEMM_GROUP_M", None)
