@@ -1361,7 +1361,9 @@ int pick_group_m(int nt, int mt, bool interleave) {
     return e ? atoi(e) : 0;
   }();
   if (env > 0) return env;
-  if (interleave) return nt <= 16 ? 4 : 6;   // (with the XCDs sharing each run of 256 tiles the choice is flat over 4 .. 8)
+  // (with the XCDs sharing each run of 256 tiles the choice is flat over 4 .. 8; one item per forward -- 17 row tiles --
+  // prefers 4 for the widest launch: linear1 414 vs 423 us)
+  if (interleave) return (nt <= 16 || (nt >= 64 && mt < 48)) ? 4 : 6;
   if (nt <= 16) return mt >= 48 ? 1 : 4;
   if (nt >= 64) return 3;
   return 4;
