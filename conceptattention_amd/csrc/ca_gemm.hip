@@ -15,7 +15,8 @@
 //    runs in registers and stores 16-byte pieces, 128 contiguous bytes per 4 lanes.
 //  * several problems share one launch (image stream + text/concept stream of a double block),
 //    tile ids are remapped so that the 32 workgroups that share an XCD (same blockIdx % 8) work
-//    on an 8(M) x 4(N) patch of tiles and reuse each other's panels in that XCD's L2.
+//    on a compact patch of tiles and reuse each other's panels in that XCD's L2 (ping-pong kernel:
+//    group_m row tiles per group, the XCDs sharing each round's 256 consecutive tiles -- pick_group_m).
 #include <stdlib.h>
 
 #include <type_traits>
