@@ -115,6 +115,10 @@ def stub_main(args):
     elapsed = D.max_over_ranks(time.perf_counter() - t0, "cpu")
     ok = all(bool((allm[j] == float(j)).all()) for j in range(n_timed))
     evidence = D.collective_evidence("cpu")   # the same record the real line carries as "collective"
+    if args.stub_evidence:   # TEST ONLY: pretend the record came from an RCCL group with this many ranks / devices
+        seen, distinct = (int(v) for v in args.stub_evidence.split(","))
+        evidence = dict(evidence or {}, backend="rccl (torch.distributed 'nccl')", ranks_seen=seen, distinct_devices=distinct)
+    D.check_collective_evidence(evidence, world)
     if rank == 0:
         print(json.dumps({"metric": "STUB (launcher test, no GPU work)", "value": n_timed * C / max(elapsed, 1e-9),
                           "workload": args.workload,
@@ -193,6 +197,8 @@ def main():
                          "per kernel kind (no events) and reported as launch_counts")
     ap.add_argument("--stub-fail-rank", type=int, default=None,
                     help="TEST ONLY (with --stub-workload): this rank exits non-zero after the rendezvous")
+    ap.add_argument("--stub-evidence", default=None,
+                    help="TEST ONLY (with --stub-workload): 'ranks_seen,distinct_devices' reported as if by an RCCL group")
     ap.add_argument("--stub-workload", action="store_true",
                     help="TEST ONLY: replace the GPU work of an item by a constant CPU tensor so that the launcher, "
                          "sharding, gather and JSON plumbing can be exercised without a GPU (gloo); the line says so")
@@ -317,7 +323,9 @@ def main():
 
     torch.cuda.synchronize()
     D.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()   # the same region on the GPU's clock (stream time from first to last launch), reported beside the wall time
     local_maps = []
     # the LAST group of --batch items runs with the per-launch HIP-event timing; the groups before it unperturbed
     n_last = min(max(1, args.batch), len(timed_items))
@@ -353,14 +361,20 @@ def main():
     else:
         # the one collective of the job: gather the small fp32 maps of all ranks in item order (RCCL over xGMI)
         all_maps = D.gather_heatmaps(local_maps, n_timed, rank, world)
+    ev1.record()
+    t_enqueued = time.perf_counter() - t0
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
+    gpu_elapsed = ev0.elapsed_time(ev1) * 1e-3
     elapsed = D.max_over_ranks(elapsed, dev)
 
     calls = n_timed
     # evidence that the job's collectives ran over `world` ranks on `world` different devices (rank 0 prints it)
     collective = D.collective_evidence(dev) if world > 1 else None
+    # ... and a group that is not what --gpus asked for ends the run non-zero instead of printing a line (every rank
+    # holds the same record, so every rank exits)
+    D.check_collective_evidence(collective, world, rehearsal=bool(os.environ.get("CA_BENCH_DEVICE")))
 
     # ---- the "concept-attention block" figure of BASELINE.json: average duration of a double block
     # (HIP events around each of the 19 block calls of one extra, untimed forward; rank 0 only)
@@ -554,6 +568,10 @@ def main():
                        **({"fp8_scope": "qkv/proj/mlp/linear1/linear2 of all blocks except double blocks "
                                         f"{layer_indices} (the heat-map layers stay bf16)"} if fp8 else {})},
             "calls_per_s": calls / elapsed,
+            "timed_region": {"wall_s": elapsed, "gpu_stream_s": gpu_elapsed, "host_enqueue_s": t_enqueued,
+                             "note": "rank 0: wall = max over ranks of barrier-to-barrier time (what value uses); "
+                                     "gpu_stream = HIP events on the launch stream around the same region; "
+                                     "host_enqueue = host time until the last launch was queued"},
             "batched_equals_single": batched_equals_single,
             **({"collective": collective} if collective is not None else {}),
             **({"launch_counts": launch_counts} if args.profile_mode else {}),

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CA_LIB_PATH: another build of the same library (A/B and diagnostic builds under tools/ab); still no fallback
 LIB_PATH = os.environ.get("CA_LIB_PATH") or os.path.join(_HERE, "libconceptattn.so")
 
-CA_VERSION = 124
+CA_VERSION = 125
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RESIDUAL, EPI_SPLIT_GELU, EPI_QKV_NORM_ROPE = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_256x256, TILE_256x192, TILE_256x128, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_PP_256x256, TILE_PP_256x128, TILE_PP_256x192 = 5, 6, 7
@@ -21,6 +21,7 @@ NORMS = {"softmax": NORM_SOFTMAX, "sparsemax": NORM_SPARSEMAX, "entmax15": NORM_
 MAX_SEGMENTS = 16
 GEMM_MAX_PROBLEMS = 2
 ATTN_MAX_PROBLEMS = 16
+HEATMAP_MAX_PROBLEMS = 16
 ATTN_Q_PRESCALED = 0.0   # ca_attn_fwd_bf16(scale=...): the q rows already carry softmax_scale * log2(e)
 
 
@@ -44,6 +45,12 @@ class AttnProblem(C.Structure):
                 ("nq", C.c_int32), ("n0", C.c_int32), ("n1", C.c_int32),
                 ("ldq", C.c_int32), ("ldo", C.c_int32), ("ldkv", C.c_int32), ("ldo32", C.c_int32),
                 ("nq0", C.c_int32), ("_pad", C.c_int32 * 3)]
+
+
+class HeatmapProblem(C.Structure):
+    _fields_ = [("img_vec", C.c_void_p), ("con_vec", C.c_void_p), ("acc", C.c_void_p), ("acc2", C.c_void_p),
+                ("logits", C.c_void_p), ("ldi", C.c_int32), ("ldc", C.c_int32), ("img_f32", C.c_int32),
+                ("con_f32", C.c_int32), ("weight", C.c_float), ("weight2", C.c_float)]
 
 
 class ModSegment(C.Structure):
@@ -92,6 +99,8 @@ SIGNATURES = {
                                                 C.c_void_p]),
     "ca_heatmap_norm_accumulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                              C.c_void_p]),
+    "ca_heatmap_fused": (C.c_int, [C.POINTER(HeatmapProblem), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p]),
     "ca_timestep_embedding_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float,
                                             C.c_void_p]),
     "ca_axpy_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),

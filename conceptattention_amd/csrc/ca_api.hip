@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "ca_common.h"
 
 static thread_local char g_err[512] = "";
@@ -12,6 +14,19 @@ void ca_set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// CU count of the current device (cached per device; a race only repeats the query); -1 if the query fails
+int ca_cu_count() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int n = cus[dev & 63].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
+    cus[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return n;
 }
 
 extern "C" int ca_version(void) { return CA_VERSION; }

@@ -126,14 +126,7 @@ int ca_attn4_launch(const AttnLaunch &L, int total, bool qk_f16, hipStream_t str
   // more units than CUs: one workgroup per CU walks them (no workgroup dispatch between units; CA_ATTN_PERSIST=0: one
   // workgroup per unit, round 3's launch)
   static const bool persist = !(getenv("CA_ATTN_PERSIST") && atoi(getenv("CA_ATTN_PERSIST")) == 0);
-  static std::atomic<int> cus[64];   // CU count per device, 0 = not asked yet (a race only repeats the query)
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  int n_cu = cus[dev & 63].load(std::memory_order_relaxed);
-  if (n_cu == 0) {
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = -1;
-    cus[dev & 63].store(n_cu, std::memory_order_relaxed);
-  }
+  const int n_cu = ca_cu_count();
   AttnLaunch LL = L;
   LL.total_units = total;
   const int grid = (persist && n_cu > 0 && n_cu % 8 == 0 && total > n_cu) ? n_cu : total;

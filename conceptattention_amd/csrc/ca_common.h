@@ -101,5 +101,6 @@ inline unsigned long long ca_device_bit() {
   return 1ull << (dev & 63);
 }
 
-// host-side error plumbing (ca_api.cpp)
+// host-side plumbing (ca_api.hip): error text; CU count of the current device (cached; -1 if the query fails)
 void ca_set_error(const char *fmt, ...);
+int ca_cu_count();

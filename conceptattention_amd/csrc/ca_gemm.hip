@@ -1370,19 +1370,6 @@ int pick_group_m(int nt, int mt, bool interleave) {
   return 4;
 }
 
-// CU count of the current device (cached per device; a race only repeats the query); -1 if the query fails
-int ca_cu_count() {
-  static std::atomic<int> cus[64];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  int n = cus[dev & 63].load(std::memory_order_relaxed);
-  if (n == 0) {
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
-    cus[dev & 63].store(n, std::memory_order_relaxed);
-  }
-  return n;
-}
-
 // Pick the tile that minimises (rounds over the 256 CUs) x (time of one round).  Round times are
 // per 48 K-steps, measured on MI355X (tools/bench_kernels.py): they only need to rank the choices.
 int auto_tile(const ca_gemm_problem *p, int n) {

@@ -545,36 +545,37 @@ __global__ __launch_bounds__(256) void ca_heatmap_logits_kernel(const IT *__rest
   }
 }
 
-// acc[c,p] += weight * softmax_c(logits[:,p])
-__global__ __launch_bounds__(256) void ca_heatmap_softmax_kernel(const float *__restrict__ logits, int C, int L,
-                                                                 float weight, float *__restrict__ acc) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= L) return;
+// The weighting across the C concepts of one patch, shared by the three-launch kernels below and the fused kernel, so
+// that both forms evaluate the same expressions.
+// softmax: v[c] = exp(z[c] - max z) for c < C, sum = their sum in c order (the caller multiplies by weight / sum).
+template <int CMAX>
+__device__ __forceinline__ void hm_softmax_terms(const float (&z)[CMAX], int C, float (&v)[CMAX], float &sum) {
   float mx = -INFINITY;
-  for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[(size_t)c * L + p]);
-  float sum = 0.f;
-  for (int c = 0; c < C; ++c) sum += __expf(logits[(size_t)c * L + p] - mx);
-  const float inv = weight / sum;
-  for (int c = 0; c < C; ++c) acc[(size_t)c * L + p] += __expf(logits[(size_t)c * L + p] - mx) * inv;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < C) mx = fmaxf(mx, z[c]);
+  sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    v[c] = c < C ? __expf(z[c] - mx) : 0.f;
+    if (c < C) sum += v[c];
+  }
 }
 
-// acc[c,p] += weight * sparsemax_c / entmax15_c (logits[:,p]): the two sparse alternatives to the softmax over
-// concepts (concept_attention_pipeline.py:66-69 calls the third-party `entmax` package for them).  Both are the
+// sparsemax_c / entmax15_c (logits[:,p]): the two sparse alternatives to the softmax over concepts
+// (concept_attention_pipeline.py:66-69 calls the third-party `entmax` package for them).  Both are the
 // published sort-and-threshold algorithms: sparsemax (Martins & Astudillo 2016, Alg. 1): z sorted descending,
 // k = max{j : 1 + j z_(j) > sum_{i<=j} z_(i)}, tau = (sum_{i<=k} z_(i) - 1) / k, p = max(z - tau, 0);
 // 1.5-entmax (Peters, Niculae & Martins 2019, Alg. 2): x = (z - max z) / 2 sorted, for every prefix j
 // mean M_j, ss_j = j (mean of squares - M_j^2), tau_j = M_j - sqrt(max((1 - ss_j) / j, 0)),
-// k = #{j : tau_j <= x_(j)}, p = max(x - tau_k, 0)^2.  One thread per patch, the C <= 16 logits in registers.
+// k = #{j : tau_j <= x_(j)}, p = max(x - tau_k, 0)^2.  The C <= CMAX logits in registers; z_in[c >= C] is ignored.
 template <int CMAX, bool ENTMAX15>
-__global__ __launch_bounds__(256) void ca_heatmap_sparse_kernel(const float *__restrict__ logits, int C, int L,
-                                                                float weight, float *__restrict__ acc) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= L) return;
+__device__ __forceinline__ void hm_sparse_terms(const float (&z_in)[CMAX], int C, float (&v)[CMAX]) {
   float z[CMAX], srt[CMAX];
   float mx = -INFINITY;
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) {
-    z[c] = c < C ? logits[(size_t)c * L + p] : -INFINITY;
+    z[c] = c < C ? z_in[c] : -INFINITY;
     mx = fmaxf(mx, z[c]);
   }
 #pragma unroll
@@ -593,7 +594,6 @@ __global__ __launch_bounds__(256) void ca_heatmap_sparse_kernel(const float *__r
     }
   float tau = 0.f;
   float cs = 0.f, cs2 = 0.f;
-  int k = 0;
 #pragma unroll
   for (int j = 0; j < CMAX; ++j) {
     if (j < C) {
@@ -611,19 +611,181 @@ __global__ __launch_bounds__(256) void ca_heatmap_sparse_kernel(const float *__r
         tj = (cs - 1.0f) / rho;
         in = 1.0f + rho * srt[j] > cs;
       }
-      if (in) {  // the support is a prefix of the sorted order, so the last j that passes is k
-        k = j + 1;
-        tau = tj;
+      if (in) tau = tj;  // the support is a prefix of the sorted order, so the last j that passes is k
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const float d = fmaxf(z[c] - tau, 0.f);
+    v[c] = c < C ? (ENTMAX15 ? d * d : d) : 0.f;
+  }
+}
+
+// acc[c,p] += weight * softmax_c(logits[:,p])
+__global__ __launch_bounds__(256) void ca_heatmap_softmax_kernel(const float *__restrict__ logits, int C, int L,
+                                                                 float weight, float *__restrict__ acc) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= L) return;
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[(size_t)c * L + p]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += __expf(logits[(size_t)c * L + p] - mx);
+  const float inv = weight / sum;
+  for (int c = 0; c < C; ++c) acc[(size_t)c * L + p] += __expf(logits[(size_t)c * L + p] - mx) * inv;
+}
+
+// acc[c,p] += weight * sparsemax_c / entmax15_c (logits[:,p]); one thread per patch.
+template <int CMAX, bool ENTMAX15>
+__global__ __launch_bounds__(256) void ca_heatmap_sparse_kernel(const float *__restrict__ logits, int C, int L,
+                                                                float weight, float *__restrict__ acc) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= L) return;
+  float z[CMAX], v[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) z[c] = c < C ? logits[(size_t)c * L + p] : -INFINITY;
+  hm_sparse_terms<CMAX, ENTMAX15>(z, C, v);
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < C) acc[(size_t)c * L + p] += weight * v[c];
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused heat maps of one layer (ca_heatmap_fused): blockIdx.y = problem (work item x space), a wave takes two patches
+// at a time: all C logits of both in one pass over their image vectors (every 16-byte piece of the two rows requested
+// before the first is used: 24 KB in flight per wave for fp32 vectors), the concept vectors fp32 in LDS (one LDS read
+// serves both patches), then lanes 0 / 1 weight their patch's C logits and update the accumulators.  Per (patch,
+// concept) the accumulation chain is ca_heatmap_logits_kernel's (lane l: k = 8 l + 512 i in i order, then the wave
+// sum), and the weighting is the three-launch kernels' expressions: bit-identical results.
+struct HeatmapLaunch {
+  ca_heatmap_problem p[CA_HEATMAP_MAX_PROBLEMS];
+  int32_t L, C, dim, norm;
+};
+constexpr int HM_PRE = 6;  // 512-element chunks of a row requested ahead (dim <= 3072 in one go)
+
+template <int CC, typename IT>
+__device__ __forceinline__ void heatmap_fused_body(const ca_heatmap_problem &P, int L, int C, int dim, int norm,
+                                                   const float *cs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const IT *img = (const IT *)P.img_vec;
+  constexpr bool F32 = std::is_same<IT, float>::value;
+  for (int p = (blockIdx.x * nw + wave) * 2; p < L; p += gridDim.x * nw * 2) {
+    const IT *ir0 = img + (size_t)p * P.ldi;
+    const IT *ir1 = img + (size_t)min(p + 1, L - 1) * P.ldi;
+    float acc0[CC], acc1[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc0[c] = acc1[c] = 0.f;
+    for (int kb = lane * 8; kb < dim; kb += 512 * HM_PRE) {
+      f32x4 u0[HM_PRE][F32 ? 2 : 1], u1[HM_PRE][F32 ? 2 : 1];   // fp32: 8 floats; bf16: 8 x bf16 in one 16-byte piece
+#pragma unroll
+      for (int i = 0; i < HM_PRE; ++i) {
+        const int k = kb + 512 * i;
+        if (k < dim) {
+          if constexpr (F32) {
+            u0[i][0] = *(const f32x4 *)(ir0 + k), u0[i][1] = *(const f32x4 *)(ir0 + k + 4);
+            u1[i][0] = *(const f32x4 *)(ir1 + k), u1[i][1] = *(const f32x4 *)(ir1 + k + 4);
+          } else {
+            u0[i][0] = *(const f32x4 *)(ir0 + k);
+            u1[i][0] = *(const f32x4 *)(ir1 + k);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < HM_PRE; ++i) {
+        const int k = kb + 512 * i;
+        if (k < dim) {
+          float a0[8], a1[8];
+          if constexpr (F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0[j] = u0[i][0][j]; a0[4 + j] = u0[i][1][j]; a1[j] = u1[i][0][j]; a1[4 + j] = u1[i][1][j]; }
+          } else {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, u0[i][0]), b1 = __builtin_bit_cast(bf16x8, u1[i][0]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a0[j] = (float)b0[j]; a1[j] = (float)b1[j]; }
+          }
+#pragma unroll
+          for (int c = 0; c < CC; ++c) {
+            const f32x4 b0 = *(const f32x4 *)(cs + c * dim + k), b1 = *(const f32x4 *)(cs + c * dim + k + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // (ca_heatmap_logits_kernel's order)
+              acc0[c] = fmaf(a0[j], b0[j], acc0[c]);
+              acc0[c] = fmaf(a0[4 + j], b1[j], acc0[c]);
+              acc1[c] = fmaf(a1[j], b0[j], acc1[c]);
+              acc1[c] = fmaf(a1[4 + j], b1[j], acc1[c]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      acc0[c] = wave_sum(acc0[c]);
+      acc1[c] = wave_sum(acc1[c]);
+    }
+    const int pp = p + lane;
+    if (lane < 2 && pp < L) {
+      float z[CC], v[CC];
+#pragma unroll
+      for (int c = 0; c < CC; ++c) z[c] = lane ? acc1[c] : acc0[c];
+      if (P.logits) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+          if (c < C) P.logits[(size_t)c * L + pp] = z[c];
+      }
+      if (norm == CA_NORM_SOFTMAX) {
+        float sum;
+        hm_softmax_terms<CC>(z, C, v, sum);
+        if (P.acc) {
+          const float inv = P.weight / sum;
+#pragma unroll
+          for (int c = 0; c < CC; ++c)
+            if (c < C) P.acc[(size_t)c * L + pp] += v[c] * inv;
+        }
+        if (P.acc2) {
+          const float inv = P.weight2 / sum;
+#pragma unroll
+          for (int c = 0; c < CC; ++c)
+            if (c < C) P.acc2[(size_t)c * L + pp] += v[c] * inv;
+        }
+      } else {
+        if (norm == CA_NORM_SPARSEMAX) hm_sparse_terms<CC, false>(z, C, v);
+        else hm_sparse_terms<CC, true>(z, C, v);
+        if (P.acc) {
+#pragma unroll
+          for (int c = 0; c < CC; ++c)
+            if (c < C) P.acc[(size_t)c * L + pp] += P.weight * v[c];
+        }
+        if (P.acc2) {
+#pragma unroll
+          for (int c = 0; c < CC; ++c)
+            if (c < C) P.acc2[(size_t)c * L + pp] += P.weight2 * v[c];
+        }
       }
     }
   }
-  (void)k;
-#pragma unroll
-  for (int c = 0; c < CMAX; ++c)
-    if (c < C) {
-      const float d = fmaxf(z[c] - tau, 0.f);
-      acc[(size_t)c * L + p] += weight * (ENTMAX15 ? d * d : d);
+}
+
+template <int CC>
+__global__ __launch_bounds__(CC <= 4 ? 256 : 512) void ca_heatmap_fused_kernel(HeatmapLaunch A) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *cs = (float *)smem_raw;  // [CC][dim]: rows >= C repeat row C - 1 (their logits are never used)
+  const ca_heatmap_problem &P = A.p[blockIdx.y];
+  const int dim = A.dim, C = A.C;
+  for (int c = 0; c < CC; ++c) {
+    const int cr = min(c, C - 1);
+    for (int k = threadIdx.x * 4; k < dim; k += blockDim.x * 4) {
+      f32x4 v;
+      if (P.con_f32) {
+        v = *(const f32x4 *)((const float *)P.con_vec + (size_t)cr * P.ldc + k);
+      } else {
+        const bf16x4 t = *(const bf16x4 *)((const bf16 *)P.con_vec + (size_t)cr * P.ldc + k);
+        v = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+      }
+      *(f32x4 *)(cs + c * dim + k) = v;
     }
+  }
+  __syncthreads();
+  if (P.img_f32) heatmap_fused_body<CC, float>(P, A.L, C, dim, A.norm, cs);
+  else heatmap_fused_body<CC, bf16>(P, A.L, C, dim, A.norm, cs);
 }
 
 __global__ __launch_bounds__(256) void ca_axpy_kernel(bf16 *__restrict__ x, const bf16 *__restrict__ y, float a,
@@ -967,6 +1129,57 @@ extern "C" int ca_heatmap_norm_accumulate(const float *logits, int32_t C, int32_
     else hipLaunchKernelGGL((ca_heatmap_sparse_kernel<16, true>), grid, block, 0, s, logits, C, L, weight, acc);
   }
   return check_launch("ca_heatmap_norm_accumulate");
+}
+
+extern "C" int ca_heatmap_fused(const ca_heatmap_problem *problems, int32_t n_problems, int32_t L, int32_t C,
+                                int32_t dim, int32_t norm, ca_stream_t stream) {
+  if (!problems || n_problems < 1 || n_problems > CA_HEATMAP_MAX_PROBLEMS || L < 1 || C < 1 || C > 8 || dim < 8 ||
+      dim % 8 || dim > 4096 || (norm != CA_NORM_SOFTMAX && norm != CA_NORM_SPARSEMAX && norm != CA_NORM_ENTMAX15)) {
+    ca_set_error("ca_heatmap_fused: bad arguments (n_problems=%d L=%d C=%d dim=%d norm=%d; need C <= 8, dim %% 8 == 0, "
+                 "dim <= 4096)", n_problems, L, C, dim, norm);
+    return CA_ERR_ARG;
+  }
+  HeatmapLaunch A = {};
+  A.L = L, A.C = C, A.dim = dim, A.norm = norm;
+  for (int i = 0; i < n_problems; ++i) {
+    const ca_heatmap_problem &p = problems[i];
+    if (!p.img_vec || !p.con_vec || (!p.acc && !p.acc2 && !p.logits) || p.ldi < dim || p.ldc < dim ||
+        p.ldi % (p.img_f32 ? 4 : 8) || p.ldc % 4 || (p.img_f32 & ~1) || (p.con_f32 & ~1) ||
+        (((uintptr_t)p.img_vec | (uintptr_t)p.con_vec) & 15) ||
+        (((uintptr_t)p.acc | (uintptr_t)p.acc2 | (uintptr_t)p.logits) & 3)) {
+      ca_set_error("ca_heatmap_fused: problem %d invalid (ldi=%d ldc=%d img_f32=%d con_f32=%d; vectors 16-byte aligned, "
+                   "at least one of acc / acc2 / logits)", i, p.ldi, p.ldc, p.img_f32, p.con_f32);
+      return CA_ERR_ARG;
+    }
+    A.p[i] = p;
+  }
+  const int cc = C <= 4 ? 4 : 8, threads = cc == 4 ? 256 : 512;
+  const size_t lds = (size_t)cc * dim * sizeof(float);
+  if (lds > 64 * 1024) {   // C > 4 at the model's dim: above the default dynamic LDS limit
+    static std::atomic<unsigned long long> attr_done{0};
+    const unsigned long long dev_bit = ca_device_bit();
+    if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
+      const hipError_t e = hipFuncSetAttribute((const void *)ca_heatmap_fused_kernel<8>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * (int)sizeof(float));
+      if (e != hipSuccess) {
+        ca_set_error("ca_heatmap_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return CA_ERR_LAUNCH;
+      }
+      attr_done.fetch_or(dev_bit, std::memory_order_release);
+    }
+  }
+  // workgroups per problem: a wave takes 2 patches per pass; about 3 (C <= 4: 48 KB of LDS each) or 2 workgroups per CU
+  // in all, so that the concept vectors are pulled into LDS a few hundred times per launch, not once per 8 patches
+  const int n_cu = ca_cu_count() > 0 ? ca_cu_count() : 256;
+  const int per_pass = threads / 64 * 2;
+  int gx = ((cc == 4 ? 3 : 2) * n_cu + n_problems - 1) / n_problems;
+  gx = gx < (L + per_pass - 1) / per_pass ? gx : (L + per_pass - 1) / per_pass;
+  if (gx < 1) gx = 1;
+  if (cc == 4)
+    hipLaunchKernelGGL(ca_heatmap_fused_kernel<4>, dim3(gx, n_problems), dim3(threads), lds, (hipStream_t)stream, A);
+  else
+    hipLaunchKernelGGL(ca_heatmap_fused_kernel<8>, dim3(gx, n_problems), dim3(threads), lds, (hipStream_t)stream, A);
+  return check_launch("ca_heatmap_fused");
 }
 
 namespace {

@@ -99,13 +99,28 @@ def collective_evidence(device, force_collective: bool = False) -> dict | None:
             bus = int(torch.cuda.get_device_properties(dev).pci_bus_id)
         except (AttributeError, RuntimeError):
             bus = -1
-    mine = torch.tensor([idx, bus], dtype=torch.int64, device=on)
-    out = torch.empty(world * 2, dtype=torch.int64, device=on)
+    # a host identifier as well: ranks on different nodes may share a local index and a bus id
+    import socket
+    import zlib
+    host = zlib.crc32(socket.gethostname().encode()) & 0x7FFFFFFF
+    mine = torch.tensor([idx, bus, host], dtype=torch.int64, device=on)
+    out = torch.empty(world * 3, dtype=torch.int64, device=on)
     dist.all_gather_into_tensor(out, mine)
-    rows = out.view(world, 2).cpu().tolist()
+    rows = out.view(world, 3).cpu().tolist()
     return {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend,
             "ranks_seen": int(one.item()), "devices": [r[0] for r in rows], "pci_bus_ids": [r[1] for r in rows],
-            "distinct_devices": len({tuple(r) for r in rows})}
+            "hosts": len({r[2] for r in rows}), "distinct_devices": len({tuple(r) for r in rows})}
+
+
+def check_collective_evidence(ev: dict | None, world: int, rehearsal: bool = False) -> None:
+    """A multi-rank run whose group is not what --gpus asked for must not print a line that looks like one (VERDICT r04
+    #7a): with the RCCL backend, ``ranks_seen`` and ``distinct_devices`` must both equal the world size.  gloo runs and
+    CA_BENCH_DEVICE rehearsals (several ranks on one GPU on purpose) are exempt (``rehearsal``)."""
+    if ev is None or world <= 1 or rehearsal or not str(ev.get("backend", "")).startswith("rccl"):
+        return
+    if ev.get("ranks_seen") != world or ev.get("distinct_devices") != world:
+        raise SystemExit(f"bench: --gpus {world} but the collectives saw {ev.get('ranks_seen')} ranks on "
+                         f"{ev.get('distinct_devices')} distinct devices: {ev}")
 
 
 def barrier():

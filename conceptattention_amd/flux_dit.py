@@ -151,8 +151,8 @@ class HeatmapRequest:
     compute_heatmaps_from_vectors later slices, concept_attention_pipeline.py:57-82)."""
     layer_indices: tuple
     weight: float                 # 1 / (|timesteps| * |layers|)
-    out_space: torch.Tensor       # fp32 [C, L] accumulator (output-space maps)
-    cross_space: torch.Tensor     # fp32 [C, L] accumulator (cross-attention-space maps)
+    out_space: Optional[torch.Tensor]     # fp32 [C, L] accumulator (output-space maps), or None (per-layer tables only)
+    cross_space: Optional[torch.Tensor]   # fp32 [C, L] accumulator (cross-attention-space maps), or None
     # optional per-layer tables [len(layer_indices), C, L] (row i = layer_indices[i]), accumulated with
     # per_layer_weight: the per-layer x per-noise-level extraction of
     # experiments/per_layer_segmentation/test_segmentations_per_layer.py:104-114 without the vector stacks
@@ -210,7 +210,11 @@ class HipFluxDiT:
         self.prescale_q = os.environ.get("CA_ATTN_PRESCALE", "1") != "0"
         # sampling.denoise keeps the latent in fp32 between the Euler steps when the model says so (A/B: CA_FP32_LATENT=0)
         self.fp32_latent = os.environ.get("CA_FP32_LATENT", "1") != "0"
-        self.f32_image_vectors = os.environ.get("CA_F32_IMAGE_VECTORS", "1") != "0"
+        # An fp32 copy of the captured layers' [text | image] attention rows for the output-space logits (round 3).  Off
+        # by default since round 5: tests/tools/diag_out_space.py measured it as worth 2e-5 on a map (stages A2 vs B) for
+        # +261 MB of writes per 5-item attention launch (1 011 vs 888 us) and 53 MB of HBM per item; the concept side keeps
+        # its fp32 rows (ATT32), which is where that rounding matters.  "1" restores it (A/B aid).
+        self.f32_image_vectors = os.environ.get("CA_F32_IMAGE_VECTORS", "0") != "0"
         # The cross-attention-space vectors (post-QKNorm, pre-RoPE q) of the captured layers from the UNROUNDED
         # LayerNorm output: the bf16 rounding of that GEMM operand is ~90 % of the cross-space heat-map error
         # (tests/tools/error_budget.py: 3.3e-3 -> 3.5e-4 per map).  The LayerNorm writes a second bf16 plane with what
@@ -233,6 +237,9 @@ class HipFluxDiT:
         self.split_q_attention = os.environ.get("CA_SPLIT_Q_ATTENTION", "1") != "0"
         # fp8 mode: the qkv projection of a layer whose maps are requested stays bf16 (_double_block)
         self.fp8_bf16_qkv_when_captured = os.environ.get("CA_FP8_QKV_BF16_CAPTURED", "1") != "0"
+        # the heat-map updates of a captured layer (all work items, both spaces) as ONE ca_heatmap_fused launch; False =
+        # logits + weighting launches per item and space (the same bits; parity / A-B aid, and what C > 8 uses)
+        self.fused_heatmaps = True
         if self.qk_f16 not in ("all", "captured", "0"):
             raise ValueError("CA_QK_F16 must be all, captured or 0")
         if not self.prescale_q or os.environ.get("CA_ATTN_KERNEL") == "8":
@@ -580,7 +587,7 @@ class HipFluxDiT:
         H = p.hidden_size
         f32 = dict(device=dev, dtype=torch.float32)
         # row order: step, item, (vec | concept_vec)
-        tv = torch.tensor([float(t) for t in timesteps for _ in range(2 * B)], **f32)
+        tv = ops.host_values([float(t) for t in timesteps for _ in range(2 * B)], dev)
         hv = torch.empty(2 * B * n, H, **f32)
         vecs = torch.empty(2 * B * n, H, **f32)
         yin = torch.empty(n, B, 2, p.vec_in_dim, **f32)
@@ -589,7 +596,7 @@ class HipFluxDiT:
         yin = yin.view(2 * B * n, -1)
         gv = None
         if p.guidance_embed:
-            gq = torch.as_tensor(guidance, **f32).reshape(-1)
+            gq = ops.host_values(guidance, dev).reshape(-1)
             gv = (gq if gq.numel() == B else gq[:1].expand(B))[None, :, None].expand(n, B, 2).reshape(-1).contiguous()
         mod = torch.empty(n, B, 2, W.mod_rows, **f32)
         mod2 = mod.view(2 * B * n, W.mod_rows)
@@ -809,6 +816,8 @@ class HipFluxDiT:
         """Dict capture (modified_double_stream_block.py:185-191) and/or fused heat-map update, per work item."""
         ATT, QPRE = self.ATT, self.QPRE
         B, C, Li, oT, oI = g.B, g.C, g.L, g.oT, g.oI
+        fused = self.fused_heatmaps and ops.heatmap_fused_fits(C, self.hidden_size)
+        launches = {}   # norm -> problems of this layer: ONE launch for all work items and both spaces
         for j in range(B if heatmaps is not None else 0):
             hm = heatmaps[j]
             if layer not in hm.layer_indices:
@@ -821,10 +830,21 @@ class HipFluxDiT:
             img_out = self.ATTI32[j, g.T:] if self._f32_image_vectors(True, heatmaps) else ATT[ij]
             for img_vec, con_vec, acc, table in ((img_out, self.ATT32[cj], hm.out_space, hm.per_layer_out),
                                                  (QPRE[ij], QPRE[cj], hm.cross_space, hm.per_layer_cross)):
+                if acc is None and table is None:
+                    continue
+                if fused:
+                    launches.setdefault(hm.norm, []).append(ops.Heatmap(
+                        img_vec, con_vec, acc, hm.weight, None if table is None else table[li], hm.per_layer_weight))
+                    continue
+                # the three-launch form (more than 8 concepts, or fused_heatmaps = False: the A/B and parity aid)
                 ops.heatmap_logits(img_vec, con_vec, self.LOGITS[:C])
-                ops.heatmap_softmax_accumulate(self.LOGITS[:C], acc, hm.weight, hm.norm)
+                if acc is not None:
+                    ops.heatmap_softmax_accumulate(self.LOGITS[:C], acc, hm.weight, hm.norm)
                 if table is not None:
                     ops.heatmap_softmax_accumulate(self.LOGITS[:C], table[li], hm.per_layer_weight, hm.norm)
+        for norm, probs in launches.items():
+            for p0 in range(0, len(probs), L.HEATMAP_MAX_PROBLEMS):
+                ops.heatmap_fused(probs[p0:p0 + L.HEATMAP_MAX_PROBLEMS], norm)
         if return_vectors:
             H = self.hidden_size
             cf = torch.contiguous_format

@@ -29,6 +29,18 @@ def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     return t
 
 
+def host_values(values, device, dtype=torch.float32) -> torch.Tensor:
+    """A few host numbers (timesteps, guidance) as a device tensor WITHOUT blocking the host: ``torch.tensor(list,
+    device=...)`` copies from pageable memory, which waits for everything queued on the stream before it -- in a loop of
+    forwards the host then cannot run ahead and the GPU idles while each forward's first launches are enqueued.  A pinned
+    staging tensor and a stream-ordered copy keep the queue full (the caching host allocator recycles the staging block
+    only after the copy has run)."""
+    t = torch.as_tensor(values, dtype=dtype)
+    if t.device.type != "cpu":
+        return t.to(device)
+    return t.reshape(-1).pin_memory().to(device, non_blocking=True).reshape(t.shape)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -433,6 +445,53 @@ def heatmap_softmax_accumulate(logits, acc, weight: float, norm: int = L.NORM_SO
         return
     L.check(lib.ca_heatmap_norm_accumulate(logits.data_ptr(), logits.shape[0], logits.shape[1], int(norm), weight,
                                            acc.data_ptr(), _stream()), "ca_heatmap_norm_accumulate")
+
+
+@dataclass
+class Heatmap:
+    """One (work item, space) problem of a fused heat-map launch: logits = img_vec @ con_vec.T per patch, then
+    acc += weight * norm_c(logits) and / or acc2 += weight2 * norm_c(logits); ``logits`` (optional) receives the raw
+    logits.  img_vec bf16|fp32 [L,dim], con_vec bf16|fp32 [C,dim], acc / acc2 / logits fp32 [C,L] contiguous."""
+    img_vec: torch.Tensor
+    con_vec: torch.Tensor
+    acc: Optional[torch.Tensor] = None
+    weight: float = 0.0
+    acc2: Optional[torch.Tensor] = None
+    weight2: float = 0.0
+    logits: Optional[torch.Tensor] = None
+
+
+def heatmap_fused_fits(C: int, dim: int) -> bool:
+    """Does ca_heatmap_fused take this geometry (all C concept vectors of a problem as fp32 in LDS)?"""
+    return 1 <= C <= 8 and dim % 8 == 0 and 8 <= dim <= 4096
+
+
+def heatmap_fused(problems: Sequence[Heatmap], norm: int = L.NORM_SOFTMAX) -> None:
+    """All heat-map updates of one layer in ONE launch (ca_heatmap_fused): bit-identical to heatmap_logits followed by
+    heatmap_softmax_accumulate per problem and accumulator."""
+    lib = L.load()
+    if not 1 <= len(problems) <= L.HEATMAP_MAX_PROBLEMS:
+        raise ValueError(f"heatmap_fused: 1..{L.HEATMAP_MAX_PROBLEMS} problems per launch")
+    arr = (L.HeatmapProblem * len(problems))()
+    Lp, dim, Cc = problems[0].img_vec.shape[0], problems[0].img_vec.shape[1], problems[0].con_vec.shape[0]
+    for i, h in enumerate(problems):
+        if h.img_vec.dtype not in (torch.bfloat16, torch.float32) or h.con_vec.dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError(f"heatmap_fused[{i}]: img_vec and con_vec must be bf16 or fp32")
+        _chk(h.img_vec, h.img_vec.dtype, "img_vec"), _chk(h.con_vec, h.con_vec.dtype, "con_vec")
+        if tuple(h.img_vec.shape) != (Lp, dim) or tuple(h.con_vec.shape) != (Cc, dim):
+            raise ValueError(f"heatmap_fused[{i}]: all problems of a launch share L, C and dim")
+        p = arr[i]
+        p.img_vec, p.con_vec, p.ldi, p.ldc = h.img_vec.data_ptr(), h.con_vec.data_ptr(), h.img_vec.stride(0), h.con_vec.stride(0)
+        p.img_f32, p.con_f32 = int(h.img_vec.dtype == torch.float32), int(h.con_vec.dtype == torch.float32)
+        for name in ("acc", "acc2", "logits"):
+            t = getattr(h, name)
+            if t is not None:
+                _chk(t, torch.float32, name)
+                if tuple(t.shape) != (Cc, Lp) or not t.is_contiguous():
+                    raise ValueError(f"heatmap_fused[{i}]: {name} must be contiguous fp32 [C,L]")
+                setattr(p, name, t.data_ptr())
+        p.weight, p.weight2 = float(h.weight), float(h.weight2)
+    L.check(lib.ca_heatmap_fused(arr, len(problems), Lp, Cc, dim, int(norm), _stream()), "ca_heatmap_fused")
 
 
 def axpy(x, y, a: float) -> None:

@@ -18,7 +18,7 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
-from . import _lib, sampling
+from . import _lib, ops, sampling
 from .flux_dit import HeatmapRequest, HipFluxDiT, on_own_device
 from .heatmaps import compute_heatmaps_from_vectors, resolve_norm
 from .params import configs
@@ -310,8 +310,7 @@ class ConceptAttentionFluxPipeline:
             grp = mine[g0:g0 + batch]
             B = len(grp)
             ts = [schedule[int(noise_levels[li])] for li in grp]
-            reqs = [HeatmapRequest(tuple(layer_indices), 0.0, torch.zeros(C, n_patches, device=self.device),
-                                   torch.zeros(C, n_patches, device=self.device), per_layer_out=out[li],
+            reqs = [HeatmapRequest(tuple(layer_indices), 0.0, None, None, per_layer_out=out[li],
                                    per_layer_cross=cross[li], per_layer_weight=1.0 / num_samples) for li in grp]
 
             def rep(t):   # the B levels are B work items of the same image
@@ -323,7 +322,7 @@ class ConceptAttentionFluxPipeline:
                 cB, idB, vB = sampling.concept_inputs(rep(con), rep(vec))
                 self.model(img=inp["img"], img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
                            concepts=cB, concept_ids=idB, concept_vec=vB, y=vB,
-                           timesteps=torch.tensor(ts, device=self.device, dtype=torch.float32),
+                           timesteps=ops.host_values(ts, self.device),
                            guidance=torch.zeros(B, device=self.device), stop_after_multimodal_attentions=True,
                            return_vectors=False, heatmaps=reqs)
         return out.view(nl, nlay, C, side, side), cross.view(nl, nlay, C, side, side)

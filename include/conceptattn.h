@@ -28,9 +28,9 @@
 extern "C" {
 #endif
 
-#define CA_VERSION 124 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
+#define CA_VERSION 125 /* 0.1.2: ca_gemm_problem.qpre_f32 / q_out_scale, fp32 image vectors in ca_heatmap_logits_bf16,
                           CA_ATTN_Q_PRESCALED; .1: ca_axpy_f32, ca_split_bf16; .2: ca_attn_stats; .3: ca_gemm_problem.qk_f16,
-                          ca_attn_fwd_qk16; .4: ca_qpre_finish_rope_f32 */
+                          ca_attn_fwd_qk16; .4: ca_qpre_finish_rope_f32; .5: ca_heatmap_fused */
 
 #define CA_OK 0
 #define CA_ERR_ARG (-1)    /* bad shape / null pointer / misalignment */
@@ -290,6 +290,29 @@ int ca_heatmap_softmax_accumulate(const float *logits, int32_t C, int32_t L, flo
 #define CA_NORM_ENTMAX15 2
 int ca_heatmap_norm_accumulate(const float *logits, int32_t C, int32_t L, int32_t norm, float weight, float *acc,
                                ca_stream_t stream);
+
+/* The three steps above for up to CA_HEATMAP_MAX_PROBLEMS (work item, space) pairs of one layer in ONE launch
+ * (round 5): per problem  logits[c,p] = <img_vec[p,:], con_vec[c,:]>  for all C concepts of a patch in one pass over
+ * the image vectors, then  acc[c,p] += weight * norm_c(logits[:,p])  and, if acc2 != NULL,
+ * acc2[c,p] += weight2 * norm_c(logits[:,p])  (the per-layer table row of the per-layer x noise-level sweep,
+ * experiments/per_layer_segmentation/test_segmentations_per_layer.py:104-114); the logits never reach memory unless
+ * `logits` != NULL.  Per patch and concept the arithmetic is that of ca_heatmap_logits_bf16 followed by
+ * ca_heatmap_norm_accumulate (same k order, same expressions): the results are bit-identical to the three-launch form.
+ * All problems of a call share L, C, dim and norm.  Needs C <= 8 and C * dim * 4 bytes of LDS (<= 96 KB);
+ * CA_ERR_ARG otherwise (the caller then uses the three-launch form). */
+#define CA_HEATMAP_MAX_PROBLEMS 16
+typedef struct {
+  const void *img_vec; /* [L, dim] bf16, or fp32 if img_f32; row stride ldi elements (% 8 bf16, % 4 fp32) */
+  const void *con_vec; /* [C, dim] bf16, or fp32 if con_f32; row stride ldc elements */
+  float *acc;          /* fp32 [C, L] contiguous, or NULL */
+  float *acc2;         /* fp32 [C, L] contiguous, or NULL */
+  float *logits;       /* fp32 [C, L] contiguous, or NULL: the raw logits as well */
+  int32_t ldi, ldc;
+  int32_t img_f32, con_f32;
+  float weight, weight2;
+} ca_heatmap_problem;
+int ca_heatmap_fused(const ca_heatmap_problem *problems, int32_t n_problems, int32_t L, int32_t C, int32_t dim,
+                     int32_t norm, ca_stream_t stream);
 
 /* Sinusoidal timestep embedding (timestep_embedding, flux/modules/layers.py:28-49):
  * out[v, 0:dim/2] = cos(time_factor*t[v]*f_i), out[v, dim/2:] = sin(...), f_i = max_period^(-i/(dim/2)). */

@@ -15,6 +15,7 @@ Fixtures
   block_full.npz                    ONE full-size double block (H=3072, L=4096, T=256, C=4)
   single_full.npz                   ONE full-size single block
   block_full_dev.npz                ONE full-size double block at the flux-dev token counts (T=512, C=8)
+  block_full_peaky.npz              the block_full case with peaky joint-attention logits (std ~8 nats; a cold text tile)
   heatmap_kat.npz                   compute_heatmaps_from_vectors known answers (softmax branch)
   sampler.npz                       get_schedule / prepare-patchify / unpack / denoise (tiny, 2 steps)
   metrics.npz                       segmentation scores of concept_attention/utils.py on seeded masks / maps
@@ -241,6 +242,100 @@ def full_block_dev(ref, out_dir):
     print("block_full_dev heat range", hm_out.min().item(), hm_out.max().item())
 
 
+def full_block_peaky(ref, out_dir):
+    """block_full's geometry and inputs with the QK-norm scales / qkv biases of oracle/full_block_case.PEAKY_CASES:
+    the joint-attention logits at std ~8 nats, and a structured case with the text tile ~20 nats below the image
+    keys.  Same outputs as block_full.npz per case (key prefix '<case>_'), plus statistics of the joint-attention
+    logits the reference's own q / k produce (recomputed here from the block's submodules)."""
+    from conceptattention_amd.params import FluxParams
+    from conceptattention_amd.weights import synthetic_state_dict
+    from oracle.full_block_case import PEAKY_CASES, full_block_inputs, peaky_state_dict
+    from concept_attention.flux.src.flux.modules.layers import EmbedND
+    from concept_attention.flux.src.flux.math import apply_rope
+    from einops import rearrange
+    p = FluxParams()
+    H, NH = p.hidden_size, p.num_heads
+    case = full_block_inputs(p)
+    base = synthetic_state_dict(p, seed=0, prefix="double_blocks.0.")
+    base = {k[len("double_blocks.0."):]: v.bfloat16().float() for k, v in base.items()}
+    emb = EmbedND(dim=128, theta=p.theta, axes_dim=list(p.axes_dim))
+    pe = emb(torch.cat((case["txt_ids"], case["img_ids"]), 1))
+    cpe = emb(torch.cat((case["concept_ids"], case["img_ids"]), 1))
+    hm_fn = ref["compute_heatmaps_from_vectors"]
+    rows = case["sample_rows"]
+    arrays = {"sample_rows": rows.numpy()}
+    for name in PEAKY_CASES:
+        sd = peaky_state_dict(base, name, H)
+        blk = ref["ModifiedDoubleStreamBlock"](H, NH, mlp_ratio=p.mlp_ratio, qkv_bias=True).eval()
+        blk.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            img, txt, con, d = blk(img=case["img"], txt=case["txt"], vec=case["vec"], pe=pe,
+                                   concepts=case["concepts"], concept_vec=case["concept_vec"], concept_pe=cpe)
+            # statistics of the joint-attention logits (heads 0, 7, 23; every 16th image query row), from the block's own
+            # submodules exactly as its forward forms q and k (modified_double_stream_block.py:88-111)
+            im1, _ = blk.img_mod(case["vec"])
+            tm1, _ = blk.txt_mod(case["vec"])
+            xi = (1 + im1.scale) * blk.img_norm1(case["img"]) + im1.shift
+            xt = (1 + tm1.scale) * blk.txt_norm1(case["txt"]) + tm1.shift
+            iq, ik, iv = rearrange(blk.img_attn.qkv(xi), "B L (K H D) -> K B H L D", K=3, H=NH)
+            iq, ik = blk.img_attn.norm(iq, ik, iv)
+            tq, tk, tv = rearrange(blk.txt_attn.qkv(xt), "B L (K H D) -> K B H L D", K=3, H=NH)
+            tq, tk = blk.txt_attn.norm(tq, tk, tv)
+            q, k = apply_rope(torch.cat((tq, iq), 2), torch.cat((tk, ik), 2), pe)
+            T = case["txt"].shape[1]
+            lg = (q[0, [0, 7, 23]][:, T::16] @ k[0, [0, 7, 23]].transpose(-1, -2)) / 128 ** 0.5   # [3, 256, T+L] nats
+            stats = np.array([lg.std().item(), (lg.max(-1).values - lg[..., :64].max(-1).values).max().item(),
+                              (lg[..., T:].mean() - lg[..., :T].mean()).item(), lg.abs().max().item()])
+        st = {k_: v[None, None] for k_, v in d.items()}
+        hm_out = hm_fn(st["output_space_image_vectors"], st["output_space_concept_vectors"],
+                       layer_indices=[0], timesteps=[0], softmax=True)
+        hm_cross = hm_fn(st["cross_attention_image_vectors"], st["cross_attention_concept_vectors"],
+                         layer_indices=[0], timesteps=[0], softmax=True)
+        logits_out = torch.einsum("bpd,bcd->bcp", d["output_space_image_vectors"], d["output_space_concept_vectors"])
+        ciq = d["cross_attention_image_vectors"].permute(0, 2, 1, 3).reshape(1, -1, H)
+        ccq = d["cross_attention_concept_vectors"].permute(0, 2, 1, 3).reshape(1, -1, H)
+        logits_cross = torch.einsum("bpd,bcd->bcp", ciq, ccq)
+        arrays.update({
+            f"{name}_heatmap_output_space": hm_out.numpy(), f"{name}_heatmap_cross_attention": hm_cross.numpy(),
+            f"{name}_logits_output_space": logits_out.numpy(), f"{name}_logits_cross_attention": logits_cross.numpy(),
+            f"{name}_concept_attn": d["output_space_concept_vectors"].numpy(),
+            f"{name}_concept_q": d["cross_attention_concept_vectors"].numpy(),
+            f"{name}_img_attn_rows": d["output_space_image_vectors"][0, rows].numpy(),
+            f"{name}_img_q_rows": d["cross_attention_image_vectors"][0, :, rows].numpy(),
+            f"{name}_img_out_rows": img[0, rows].numpy(), f"{name}_txt_out": txt[0, ::8].numpy(),
+            f"{name}_concepts_out": con.numpy(),
+            f"{name}_joint_logit_stats": stats,   # [std, max over rows of (row max - max of its first 64 keys), mean image key - mean text key, max |logit|] in nats
+            f"{name}_key_scale_checksum": _checksum(sd["img_attn.norm.key_norm.scale"]),
+        })
+        # the yardstick of DESIGN.md section 2: the REFERENCE's own block in bf16 (its production dtype) on the same
+        # weights and inputs, its vectors reduced in fp32 -- how far a bf16 run is from the fp32 values above
+        bf = torch.bfloat16
+        blk16 = ref["ModifiedDoubleStreamBlock"](H, NH, mlp_ratio=p.mlp_ratio, qkv_bias=True).eval()
+        blk16.load_state_dict(sd, strict=True)
+        blk16 = blk16.to(bf)
+        with torch.no_grad():
+            i16, t16, c16, d16 = blk16(img=case["img"].to(bf), txt=case["txt"].to(bf), vec=case["vec"].to(bf), pe=pe,
+                                       concepts=case["concepts"].to(bf), concept_vec=case["concept_vec"].to(bf),
+                                       concept_pe=cpe)
+        st16 = {k_: v.float()[None, None] for k_, v in d16.items()}
+        h16o = hm_fn(st16["output_space_image_vectors"], st16["output_space_concept_vectors"], layer_indices=[0],
+                     timesteps=[0], softmax=True)
+        h16c = hm_fn(st16["cross_attention_image_vectors"], st16["cross_attention_concept_vectors"], layer_indices=[0],
+                     timesteps=[0], softmax=True)
+        arrays[f"{name}_refbf16_err"] = np.array([
+            (h16o - hm_out).abs().max().item(), (h16c - hm_cross).abs().max().item(),
+            (d16["output_space_concept_vectors"].float() - d["output_space_concept_vectors"]).abs().max().item(),
+            (d16["output_space_image_vectors"].float() - d["output_space_image_vectors"]).abs().max().item(),
+            (i16.float() - img).abs().max().item()])   # [map out, map cross, concept_attn, img_attn, img_out] max-abs
+        print(f"block_full_peaky[{name}]: reference in bf16 vs fp32: ", arrays[f"{name}_refbf16_err"])
+        del blk16
+        print(f"block_full_peaky[{name}]: joint logits std {stats[0]:.2f} nats, late-max gap {stats[1]:.1f}, image - text "
+              f"{stats[2]:.1f}, max |logit| {stats[3]:.1f}; heat range {hm_out.min().item():.4f} .. {hm_out.max().item():.4f}, "
+              f"cross {hm_cross.min().item():.4f} .. {hm_cross.max().item():.4f}")
+        del blk
+    np.savez_compressed(os.path.join(out_dir, "block_full_peaky.npz"), **arrays)
+
+
 def heatmap_kat(ref, out_dir):
     fn = ref["compute_heatmaps_from_vectors"]
     g = torch.Generator().manual_seed(11)
@@ -355,7 +450,7 @@ def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     ref = _import_reference()
-    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "metrics", "full", "fulldev", "temb"]
+    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "metrics", "full", "fulldev", "temb", "peaky"]
     if "tiny" in which:
         tiny_model(ref, out_dir, False, "tiny_schnell.npz")
         tiny_model(ref, out_dir, True, "tiny_dev.npz")
@@ -373,6 +468,8 @@ def main():
         full_blocks(ref, out_dir)
     if "fulldev" in which:
         full_block_dev(ref, out_dir)
+    if "peaky" in which:
+        full_block_peaky(ref, out_dir)
 
 
 if __name__ == "__main__":

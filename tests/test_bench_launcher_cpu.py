@@ -62,3 +62,29 @@ def test_world_size_mismatch_is_rejected():
     r = _run(["--gpus", "1", "--stub-workload"], {"WORLD_SIZE": "2", "RANK": "0", "MASTER_ADDR": "127.0.0.1",
                                                   "MASTER_PORT": "1"}, timeout=120)
     assert r.returncode != 0
+
+
+def test_a_group_that_is_not_what_gpus_asked_for_ends_the_run_non_zero():
+    """VERDICT r04 #7a: with the RCCL backend, ranks_seen != --gpus or distinct_devices != --gpus (all ranks on one GPU; a
+    group smaller than asked) must not produce a result line.  The record is overridden through --stub-evidence, the
+    check is the one the real path runs (distributed.check_collective_evidence)."""
+    ok = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--stub-workload", "--stub-evidence", "2,2"])
+    assert ok.returncode == 0 and [l for l in ok.stdout.splitlines() if l.startswith("{")], ok.stderr[-1500:]
+    for bad in ("2,1", "1,2"):
+        r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--stub-workload", "--stub-evidence", bad])
+        assert r.returncode != 0, bad
+        assert "distinct devices" in (r.stderr + r.stdout)
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_check_collective_evidence_rules():
+    from conceptattention_amd import distributed as D
+    rccl = {"backend": "rccl (torch.distributed 'nccl')", "ranks_seen": 8, "distinct_devices": 8}
+    D.check_collective_evidence(rccl, 8)
+    D.check_collective_evidence(None, 1)
+    D.check_collective_evidence({"backend": "gloo", "ranks_seen": 2, "distinct_devices": 1}, 2)      # gloo rehearsal
+    D.check_collective_evidence(dict(rccl, distinct_devices=1), 8, rehearsal=True)                   # CA_BENCH_DEVICE
+    with pytest.raises(SystemExit):
+        D.check_collective_evidence(dict(rccl, distinct_devices=7), 8)
+    with pytest.raises(SystemExit):
+        D.check_collective_evidence(dict(rccl, ranks_seen=4), 8)

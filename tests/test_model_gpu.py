@@ -5,6 +5,7 @@ with fp32 accumulation; the oracle is fp32 on the SAME bf16-representable weight
 Heat maps (softmax over concepts, values in [0,1]) must agree to <= 1e-3 max-abs per block;
 activations to a few bf16 ulps of their magnitude."""
 
+import numpy as np
 import pytest
 import torch
 
@@ -162,14 +163,17 @@ def test_argument_errors_match_reference():
         m.load_state_dict({"nope": torch.zeros(1)})
 
 
-def _full_block_model(prefix_kind, T=256, C=4, seed=7):
-    """A HipFluxDiT holding ONE full-size block (H=3072) with the golden case's weights."""
+def _full_block_model(prefix_kind, T=256, C=4, seed=7, sd_transform=None):
+    """A HipFluxDiT holding ONE full-size block (H=3072) with the golden case's weights (``sd_transform``: applied to
+    the block's state dict, names without the block prefix)."""
     from oracle.full_block_case import full_block_inputs
     p = FluxParams(depth=1 if prefix_kind == "double" else 0, depth_single_blocks=0 if prefix_kind == "double" else 1)
     case = full_block_inputs(p, T=T, C=C, seed=seed)
     m = HipFluxDiT(p, DEV)
     pref = "double_blocks.0." if prefix_kind == "double" else "single_blocks.0."
     sd = synthetic_state_dict(p, seed=0, prefix=pref)
+    if sd_transform is not None:
+        sd = {pref + k: v for k, v in sd_transform({k[len(pref):]: v.bfloat16().float() for k, v in sd.items()}).items()}
     m.load_state_dict(sd, strict=False)
     L = 4096
     m._workspace(L, T, C)
@@ -227,6 +231,73 @@ def test_full_size_double_block_vs_reference_golden(golden):
     # dict capture shapes = the reference's (modified_double_stream_block.py:185-191)
     assert tuple(out["output_space_image_vectors"][0].shape) == (1, L, 3072)
     assert tuple(out["cross_attention_image_vectors"][0].shape) == (1, 24, L, 128)
+
+
+PEAKY_MEASURED = {}
+# max-abs vs the reference's fp32 block, <= 1.5 x measured on MI355X (profiles/r05_peaky_block_parity.json; the worse of
+# the two q / k storage types); the reference's own bf16 run: iid8 2.3e-2 / 8.6e-3 / 1.4e-2 / 3.9e-2 / 2.9e-2,
+# coldtext 8.4e-3 / 4.7e-3 / 5.2e-3 / 2.1e-2 / 3.0e-2
+PEAKY_BOUNDS = {"iid8": {"heatmap_out": 2.3e-2, "heatmap_cross": 1e-3, "concept_attn_f32": 1.5e-2, "img_attn_rows": 4e-2,
+                         "img_out_rows": 3e-2},
+                "coldtext": {"heatmap_out": 8.5e-3, "heatmap_cross": 1e-3, "concept_attn_f32": 5.2e-3,
+                             "img_attn_rows": 2.1e-2, "img_out_rows": 3e-2}}
+
+
+@pytest.mark.parametrize("qk_f16", ["captured", "0"])
+@pytest.mark.parametrize("case_name", ["iid8", "coldtext"])
+def test_full_size_double_block_peaky_logits_vs_reference_golden(golden, case_name, qk_f16):
+    """The block_full case at peaky joint-attention logits (round 5; VERDICT r04 weak #2: every other model-level parity
+    number lives on logits of std ~1 nat): tests/golden/block_full_peaky.npz is the REFERENCE's block on the same
+    weights with the key-norm scales x 8 (std 7.3 nats, row maxima up to 22 nats above the first key tile's) and a
+    structured case (every image query sees the whole text tile ~15 nats below its image keys).  Here the fused QK-norm
+    epilogue, the pre-scaled q, the half-precision q / k of a captured layer (|k| up to ~200) and the fp32 concept rows
+    all see other magnitudes than anywhere else in the suite.  Same gates as the std-1 case above."""
+    from oracle.full_block_case import peaky_state_dict
+    g = golden("block_full_peaky.npz")
+    G = lambda k: g[f"{case_name}_{k}"]   # noqa: E731
+    m, case, (L, T, C) = _full_block_model("double", sd_transform=lambda sd: peaky_state_dict(sd, case_name, 3072))
+    m.qk_f16 = qk_f16
+    out = {k: [] for k in DICT_KEYS}
+    req = HeatmapRequest((0,), 1.0, torch.zeros(C, L, device=DEV), torch.zeros(C, L, device=DEV))
+    ops.attention_stats(reset=True)
+    m._double_block(0, _Geom(1, C, T, L), None, out, True, [req])
+    torch.cuda.synchronize()
+    stats = ops.attention_stats()
+    rows = torch.from_numpy(g["sample_rows"]).to(DEV)
+    CT = C + T
+    e = {"concept_attn_f32": maxabs(m.ATT32[:C], G("concept_attn")[0]),
+         "img_attn_rows": maxabs(m.ATT[CT:][rows], G("img_attn_rows")),
+         "concept_q": maxabs(m.QPRE[:C].view(C, 24, 128).permute(1, 0, 2), G("concept_q")[0]),
+         "img_q_rows": maxabs(m.QPRE[CT:].view(L, 24, 128).permute(1, 0, 2)[:, rows], G("img_q_rows")),
+         "heatmap_out": maxabs(req.out_space.view(C, 64, 64), G("heatmap_output_space")[0]),
+         "heatmap_cross": maxabs(req.cross_space.view(C, 64, 64), G("heatmap_cross_attention")[0]),
+         "img_out_rows": maxabs(m.X[CT:][rows], G("img_out_rows")),
+         "txt_out": maxabs(m.X[C:CT][::8], G("txt_out")), "concepts_out": maxabs(m.X[:C], G("concepts_out")[0]),
+         "recomputed_workgroups": stats["recomputed_workgroups"], "rereference_events": stats["rereference_events"],
+         "ref_max_abs_img_attn": float(np.abs(G("img_attn_rows")).max())}
+    PEAKY_MEASURED[f"{case_name}/qk_f16={qk_f16}"] = e
+    print(f"\n[measured] peaky block {case_name} qk_f16={qk_f16}: {e}")
+    if len(PEAKY_MEASURED) == 4:
+        import json
+        import os
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(PEAKY_MEASURED, open("gpurun_out/r05_peaky_block_parity.json", "w"), indent=1)
+    # Gates.  A peaky attention row returns (almost) single value vectors, so the 2^-9 relative rounding of v, of P and of
+    # the rotated k no longer averages out over 4 352 keys as it does at std 1: NO bf16 path holds 1e-3 on this map.  The
+    # yardstick is DESIGN.md section 2's: the REFERENCE's own block run in bf16 on the same numbers (stored beside the
+    # fp32 values by oracle/make_goldens.py: output map, cross map, concept rows, image rows, residual rows), and the
+    # HIP path must be at least as close to fp32 as that, plus absolute bounds <= 1.5 x measured (PEAKY_BOUNDS).
+    y = dict(zip(("heatmap_out", "heatmap_cross", "concept_attn_f32", "img_attn_rows", "img_out_rows"), G("refbf16_err")))
+    e["reference_bf16"] = {k: float(v) for k, v in y.items()}
+    for k, yref in y.items():
+        assert e[k] <= max(1e-3, float(yref)), (k, e[k], float(yref))
+        assert e[k] <= PEAKY_BOUNDS[case_name][k], (k, e[k])
+    assert e["concept_q"] < 4e-3 and e["img_q_rows"] < 4e-3
+    cm = req.cross_space.view(C, 64, 64).cpu()
+    ref_cm = torch.from_numpy(G("heatmap_cross_attention")[0])
+    assert (cm.argmax(0) == ref_cm.argmax(0)).float().mean().item() > 0.99
+    assert e["txt_out"] < 6e-2 and e["concepts_out"] < 6e-2
+    assert stats["recomputed_workgroups"] == 0  # the in-place re-reference takes these distributions (ca_attn_stats)
 
 
 def test_full_size_single_block_vs_reference_golden(golden):

@@ -147,6 +147,43 @@ def test_full_size_blocks(golden):
     assert _maxabs(y[0, _t(gs["sample_rows"])], gs["out_rows"]) < 2e-4
 
 
+@pytest.mark.parametrize("case_name", ["iid8", "coldtext"])
+def test_full_size_block_peaky_logits(golden, case_name):
+    """block_full's case with peaky joint-attention logits (oracle/full_block_case.PEAKY_CASES: std ~7 nats; a text tile
+    ~15 nats below the image keys), made by the reference's own block (oracle/make_goldens.py peaky)."""
+    from oracle.full_block_case import full_block_inputs, peaky_state_dict
+    g = golden("block_full_peaky.npz")
+    p = FluxParams()
+    case = full_block_inputs(p)
+    base = {k[len("double_blocks.0."):]: v.bfloat16().float()
+            for k, v in synthetic_state_dict(p, seed=0, prefix="double_blocks.0.").items()}
+    sd = {"double_blocks.0." + k: v for k, v in peaky_state_dict(base, case_name, p.hidden_size).items()}
+    rope_ti = O.rope_cos_sin(torch.cat((case["txt_ids"][0], case["img_ids"][0])), p.axes_dim, p.theta)
+    rope_ci = O.rope_cos_sin(torch.cat((case["concept_ids"][0], case["img_ids"][0])), p.axes_dim, p.theta)
+    img, txt, con, d = O.double_block(sd, "double_blocks.0.", p.num_heads, case["img"], case["txt"], case["vec"],
+                                      rope_ti, case["concepts"], case["concept_vec"], rope_ci)
+    rows = _t(g["sample_rows"])
+    G = lambda k: g[f"{case_name}_{k}"]   # noqa: E731
+    stats = G("joint_logit_stats")
+    assert stats[0] > 4.0 and stats[1] > 20.0          # the case IS peaky: std, late-maximum gap in nats
+    assert _maxabs(d["output_space_concept_vectors"], G("concept_attn")) < 2e-5
+    assert _maxabs(d["cross_attention_concept_vectors"], G("concept_q")) < 1e-5
+    assert _maxabs(d["output_space_image_vectors"][0, rows], G("img_attn_rows")) < 2e-5
+    assert _maxabs(d["cross_attention_image_vectors"][0, :, rows], G("img_q_rows")) < 1e-5
+    assert _maxabs(img[0, rows], G("img_out_rows")) < 2e-4
+    assert _maxabs(txt[0, ::8], G("txt_out")) < 2e-4
+    assert _maxabs(con, G("concepts_out")) < 2e-4
+    st = {k: v[None, None] for k, v in d.items()}
+    lo = O.heatmap_logits(st["output_space_image_vectors"], st["output_space_concept_vectors"])[0, 0]
+    assert _maxabs(lo, G("logits_output_space")) < 2e-4
+    hm = O.compute_heatmaps(st["output_space_image_vectors"], st["output_space_concept_vectors"], [0], [0])
+    assert _maxabs(hm, G("heatmap_output_space")) < 2e-5
+    lc = O.heatmap_logits(st["cross_attention_image_vectors"], st["cross_attention_concept_vectors"])[0, 0]
+    assert _maxabs(lc, G("logits_cross_attention")) < 1e-4
+    cm = O.compute_heatmaps(st["cross_attention_image_vectors"], st["cross_attention_concept_vectors"], [0], [0])
+    assert _maxabs(cm, G("heatmap_cross_attention")) < 1e-4
+
+
 def test_full_size_block_dev_token_counts(golden):
     """T=512 text tokens, C=8 concepts (BASELINE.json configs[2] geometry), one full-size double block."""
     from oracle.full_block_case import full_block_inputs
