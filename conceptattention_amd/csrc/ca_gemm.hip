@@ -46,7 +46,15 @@ struct GemmLaunch {
   // thin-row kernel (a thin last row tile under the 256x256 bf16 ping-pong tile): 32 x 128 tiles
   int32_t thin_row0[CA_GEMM_MAX_PROBLEMS];   // first row of the problem's thin part
   int32_t thin_nt[CA_GEMM_MAX_PROBLEMS];     // its 128-column tiles (N / 128), 0 = none
+  int32_t queue_slot;     // persistent walk: -1 = fixed stride of the grid; else the row of ca_gemm_queue the workgroups
+                          // of an XCD draw their next tile from (experiment, round 5: CA_GEMM_QUEUE=1)
 };
+
+// Dynamic tile queue of the persistent walk (experiment): per launch one row of counters, [0..7] = tiles handed out per
+// XCD class beyond each workgroup's first, [8] = workgroups that have left; the last one to leave zeroes the row, so a
+// row is ready again when its launch has ended (rows are dealt round-robin by the host: 256 launches may be in flight).
+constexpr int CA_GEMM_QSLOTS = 256;
+__device__ unsigned int ca_gemm_queue[CA_GEMM_QSLOTS][16];
 
 // A last row tile with at most this many valid rows is "thin": its MFMAs on row fragments past M are skipped (the
 // K loop is then paced by the staging and the barriers, about half a tile time), and it is walked last so that it
@@ -1004,7 +1012,31 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
 template <int NL, int NHI, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) {
   extern __shared__ __attribute__((aligned(128))) char smem[];
-  if (L.persist_tiles > 0) {
+  if (L.persist_tiles > 0 && L.queue_slot >= 0) {
+    // dynamic walk: a workgroup's tiles keep its XCD class (tile v = 8 k + x on XCD x, as with the fixed stride), but
+    // the k-th tile of a class goes to whichever of the XCD's workgroups asks first.  The request for the NEXT tile is
+    // issued before this tile starts and read after it (no exposed round trip); s_next is double-buffered by parity.
+    __shared__ int s_next[2];
+    unsigned int *q = ca_gemm_queue[L.queue_slot];
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+    int v = blockIdx.x, par = 0;
+    while (v < L.persist_tiles) {
+      unsigned int nxt = 0;
+      if (threadIdx.x == 0) nxt = atomicAdd(&q[xcd], 1u);
+      ca_gemm_pp_tile<NL, NHI, FP8>(L, smem, v, L.persist_tiles);
+      if (threadIdx.x == 0) s_next[par] = (int)(nxt + (unsigned)per) * 8 + xcd;
+      __syncthreads();
+      v = s_next[par];
+      par ^= 1;
+    }
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(&q[8], 1u) == gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicExch(&q[i], 0u);
+      }
+    }
+  } else if (L.persist_tiles > 0) {
     for (int v = blockIdx.x; v < L.persist_tiles; v += gridDim.x) {
       ca_gemm_pp_tile<NL, NHI, FP8>(L, smem, v, L.persist_tiles);
       __syncthreads();
@@ -1370,9 +1402,23 @@ int pick_group_m(int nt, int mt, bool interleave) {
   return 4;
 }
 
-// Pick the tile that minimises (rounds over the 256 CUs) x (time of one round).  Round times are
+// Do the thin last-row tiles of a launch ride in the ping-pong walk (in the CUs the main tiles leave idle in their last
+// round) instead of getting the thin-row kernel's own launch?  ONE predicate for the tile chooser and for gemm_impl
+// (CA_GEMM_THIN_INWALK=0: never; round 3's behaviour, A/B aid).
+bool thin_rides_in_walk(long main_all, long thin_all, int n_cu) {
+  static const int inwalk_env = [] { const char *e = getenv("CA_GEMM_THIN_INWALK"); return e ? atoi(e) : 1; }();
+  return inwalk_env && n_cu > 0 && thin_all > 0 && main_all % n_cu != 0 && main_all % n_cu + thin_all <= n_cu;
+}
+
+bool thin_kernel_enabled() {   // CA_GEMM_THIN_KERNEL=0: thin rows stay 256-column tiles of the ping-pong walk (A/B aid)
+  static const int env = [] { const char *e = getenv("CA_GEMM_THIN_KERNEL"); return e ? atoi(e) : 1; }();
+  return env != 0;
+}
+
+// Pick the tile that minimises (rounds over the CUs) x (time of one round).  Round times are
 // per 48 K-steps, measured on MI355X (tools/bench_kernels.py): they only need to rank the choices.
 int auto_tile(const ca_gemm_problem *p, int n) {
+  const int n_cu = ca_cu_count() > 0 ? ca_cu_count() : 256;
   static const struct { int tile; double round_us; } cands[] = {
       {CA_TILE_PP_256x256, 80.0}, {CA_TILE_PP_256x192, 70.5}, {CA_TILE_PP_256x128, 51.0}, {CA_TILE_256x64, 35.0}};
   int best = 0;
@@ -1401,8 +1447,8 @@ int auto_tile(const ca_gemm_problem *p, int n) {
       if (p[i].K > kmax) kmax = p[i].K;
     }
     if (!ok) continue;
-    // makespan estimate: at least one longest tile, at least the K-weighted work spread over 256 CUs
-    double rounds = work / kmax / 256.0;
+    // makespan estimate: at least one longest tile, at least the K-weighted work spread over the CUs
+    double rounds = work / kmax / (double)n_cu;
     rounds = work == 0 ? 0.0 : rounds <= 1.0 ? 1.0 : (double)(long)(rounds + 0.999);
     // the thin-row launch behind the main one: measured 0.3 of a 256x256 round at its K (profiles/r02_remainder_probe.txt)
     // -- unless the thin tiles fit into the CUs the main tiles leave idle in their last round (gemm_impl's thin_fits):
@@ -1416,7 +1462,8 @@ int auto_tile(const ca_gemm_problem *p, int n) {
         main_t += ((p[i].M + 255) / 256 - thin) * (long)(p[i].N / 256);
         thin_t += thin * (long)(p[i].N / 256);
       }
-      if (main_t % 256 != 0 && main_t % 256 + thin_t <= 256) thin_cost = 0.0;
+      if (thin_rides_in_walk(main_t, thin_t, n_cu)) thin_cost = 0.0;
+      else if (!thin_kernel_enabled()) thin_cost = 0.75 * c.round_us * thin_k;   // full-width thin tiles after the walk
     }
     const double cost = rounds * c.round_us * kmax + thin_cost;
     if (cost < best_cost) {
@@ -1551,17 +1598,17 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
     L.mt[1] = L.nt[1] = 1;
     L.p[1] = L.p[0];
   }
-  static const int thin_kernel_env = [] {
-    const char *e = getenv("CA_GEMM_THIN_KERNEL");  // 0: thin rows stay 256-column tiles of the ping-pong walk (A/B aid)
-    return e ? atoi(e) : 1;
-  }();
+  const bool thin_kernel_env = thin_kernel_enabled();
   // the 8 XCDs share each run of 256 consecutive tiles of the order (XCD x: its tiles 32 x .. 32 x + 31) instead of
   // owning one eighth of the order each: all of them stream the same group of A rows at a time (CA_GEMM_XCD_INTERLEAVE=0:
   // rounds 1-3's contiguous ranges)
-  static const int xil = [] { const char *e = getenv("CA_GEMM_XCD_INTERLEAVE"); return e ? atoi(e) : 1; }();
+  static const int xil_env = [] { const char *e = getenv("CA_GEMM_XCD_INTERLEAVE"); return e ? atoi(e) : 1; }();
+  const int n_cu = ca_cu_count();
+  // (the order's "round" is 256 tiles = 32 per XCD, which is what runs together only on a 256-CU part: elsewhere the
+  // contiguous ranges, whose mapping does not assume a grid size)
+  const int xil = xil_env && n_cu == 256;
   L.xcd_interleave = xil;
   L.group_m = pick_group_m(L.nt[0], L.mt[0], xil != 0);
-  const int n_cu = ca_cu_count();
   // Thin last row tiles (<= CA_GEMM_THIN_ROWS valid rows) under the bf16 256x256 tile normally get their own launch of
   // 32 x 128 tiles behind the main one (ca_gemm_thin_kernel).  But when the main tiles leave enough CUs idle in their
   // last round for every thin tile -- the one-item forward: 204 + 12 tiles on 256 CUs -- the thin tiles ride in the walk
@@ -1574,12 +1621,7 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
     main_all += (L.mt[i] - thin) * L.nt[i];
     thin_all += thin * L.nt[i];
   }
-  static const int thin_inwalk_env = [] {
-    const char *e = getenv("CA_GEMM_THIN_INWALK");   // 0: thin rows always leave the walk (round 3's behaviour; A/B aid)
-    return e ? atoi(e) : 1;
-  }();
-  const bool thin_fits = thin_inwalk_env && n_cu > 0 && thin_all > 0 && main_all % n_cu != 0 &&
-                         main_all % n_cu + thin_all <= n_cu;
+  const bool thin_fits = thin_rides_in_walk(main_all, thin_all, n_cu);
   int total_pp = 0;
   for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i) {  // tile order of the ping-pong kernel: thin last row tiles go last
     const int rem = i < n_problems ? L.p[i].M % 256 : 0;
@@ -1604,9 +1646,13 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
       return e ? atoi(e) : 1;
     }();
     const int n = n_cu;
+    L.queue_slot = -1;
     if (persist_env && n > 0 && n % 8 == 0 && total > n) {
       L.persist_tiles = total;
       L.persist_tiles_grid = n;
+      static const int queue_env = [] { const char *e = getenv("CA_GEMM_QUEUE"); return e ? atoi(e) : 0; }();
+      static std::atomic<unsigned> next_slot{0};
+      if (queue_env) L.queue_slot = (int)(next_slot.fetch_add(1, std::memory_order_relaxed) % CA_GEMM_QSLOTS);
     }
   }
   if (fp8) return launch_pp<2, 2, true>(L, total, s);

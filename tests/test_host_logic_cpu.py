@@ -139,3 +139,54 @@ def test_every_attribute_the_model_reads_is_assigned_somewhere():
                 set(re.findall(r"([A-Z][A-Z0-9_]*)=torch\.zeros", cls)))
     missing = sorted(used - assigned - {"__dict__"})
     assert missing == [], missing
+
+
+def _pp_tile_of(bid, main_total, ntiles_main, mt_main, nt, group_m, xcd_interleave, nthin, mt):
+    """Python model of ca_gemm_pp_tile's tile order (conceptattention_amd/csrc/ca_gemm.hip: bid -> (problem, row tile,
+    column tile)); kept beside the kernel's arithmetic line for line."""
+    if bid < main_total:
+        xcd = bid & 7
+        if xcd_interleave and bid < (main_total & ~255):
+            lid = (bid & ~255) + 32 * xcd + ((bid >> 3) & 31)
+        else:
+            base = (main_total & ~255) if xcd_interleave else 0
+            tot, b = main_total - base, bid - base
+            q8, r8 = tot >> 3, tot & 7
+            lid = base + (xcd * (q8 + 1) if xcd < r8 else r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3)
+        prob = 1 if lid >= ntiles_main[0] else 0
+        if prob:
+            lid -= ntiles_main[0]
+        MT, NT = mt_main[prob], nt[prob]
+        grp = lid // (group_m * NT)
+        first_m = grp * group_m
+        gm = min(group_m, MT - first_m)
+        in_grp = lid - grp * group_m * NT
+        return prob, first_m + in_grp % gm, in_grp // gm
+    u = bid - main_total
+    prob = 1 if u >= nthin[0] else 0
+    if prob:
+        u -= nthin[0]
+    return prob, mt[prob] - 1, u
+
+
+def test_gemm_tile_order_is_a_bijection_for_any_tile_count():
+    """the XCD-interleaved order assumes runs of 256 tiles; the mapping must stay a bijection onto the
+    (problem, row tile, column tile) set for every main_total (multiples of 256 or not), group height, column count,
+    with and without thin tiles, interleave on or off -- whatever grid walks it."""
+    import itertools
+    for (mt0, mt1), NT, gm, xil, thin in itertools.product(
+            [(17, 2), (80, 6), (5, 0), (1, 1), (33, 7), (86, 0)], [1, 12, 36, 48, 84], [1, 3, 4, 6, 8], [0, 1], [0, 1]):
+        mt = [mt0, max(mt1, 1)]
+        has1 = mt1 > 0
+        nthin = [0, NT if (thin and has1) else 0]
+        mt_main = [mt[0], (mt[1] - (1 if nthin[1] else 0)) if has1 else 1]
+        ntiles_main = [mt_main[0] * NT, mt_main[1] * NT if has1 else 0]
+        main_total = sum(ntiles_main)
+        total = main_total + sum(nthin)
+        seen = {_pp_tile_of(b, main_total, ntiles_main, mt_main, [NT, NT], gm, xil, nthin, mt) for b in range(total)}
+        want = {(0, m, n) for m in range(mt_main[0]) for n in range(NT)}
+        if has1:
+            want |= {(1, m, n) for m in range(mt_main[1]) for n in range(NT)}
+            if nthin[1]:
+                want |= {(1, mt[1] - 1, n) for n in range(NT)}
+        assert seen == want, (mt0, mt1, NT, gm, xil, thin, len(seen), len(want))

@@ -1,6 +1,8 @@
 set -e
-O=gpurun_out/r05e; mkdir -p $O
-for n in 5 10 20 10; do
+O=gpurun_out/r05f; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || (tail -30 $O/tests.log; exit 1)
+tail -3 $O/tests.log
+for n in 10 20; do
 python3 bench.py --workload sweep --steps $n --warmup 1 --no-cpu-baseline --no-kernel-timing --no-solo-check --no-block-timing > $O/s${n}.json 2>>$O/err.txt
 python3 -c "
 import json; d=json.load(open('$O/s$n.json')); print('sweep steps $n', d['ms_per_step'], d['timed_region'])"
@@ -11,5 +13,3 @@ import json; d=json.load(open('$O/encode.json')); print('encode', d['ms_per_step
 python3 bench.py --steps 10 --warmup 1 --no-cpu-baseline > $O/default.json 2>>$O/err.txt
 python3 -c "
 import json; d=json.load(open('$O/default.json')); print('default', d['value'], d['ms_per_step'], d['timed_region'])"
-python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1
-tail -3 $O/tests.log
