@@ -506,9 +506,7 @@ def main():
         if attn_records:   # second MFMA kernel of the path, timed the same way on the same solo step
             fl = sum(r[0] for r in attn_records)
             sec = sum(r[1].elapsed_time(r[2]) for r in attn_records) * 1e-3
-            attn_kernel = ("ca_attn_kernel<8> (two waves per SIMD, 256 query rows x 64-key tiles)"
-                           if os.environ.get("CA_ATTN_KERNEL") == "8" else
-                           "ca_attn4_kernel (one wave per SIMD, 4 x 64 query rows x 64-key tiles, generated stream)")
+            attn_kernel = "ca_attn4_kernel (one wave per SIMD, 4 x 64 query rows x 64-key tiles, generated stream)"
             roof_attn = {"bound": "mfma", "kernel": attn_kernel,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": len(attn_records),
                          "avg_launch_us": sec / len(attn_records) * 1e6, "flops_per_launch": fl / len(attn_records),

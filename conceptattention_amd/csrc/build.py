@@ -285,7 +285,10 @@ def audit_asm_statements(text: str) -> list:
     return sorted(set(bad))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, defines=(), out: str | None = None) -> str:
+    """The product library (in-tree), or with ``defines`` / ``out`` a diagnostic build elsewhere (build_ab)."""
+    if out is not None or defines:
+        return _build_variant(list(defines), out or LIB, verbose)
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -310,5 +313,39 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+AB_LIB = os.path.join(os.path.dirname(PKG), "tools", "ab", "switches", "libca.so")
+
+
+def _build_variant(defines, out, verbose):
+    """Objects next to ``out`` (never over the product's), same flags and the same ca_attn4 audit."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    odir = os.path.dirname(os.path.abspath(out))
+    os.makedirs(odir, exist_ok=True)
+    objs, procs = [], []
+    for s in SOURCES:
+        o = os.path.join(odir, s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + [f"-D{d}" for d in defines] + \
+              [f for f in EXTRA_FLAGS.get(s, []) if not f.startswith("-save-temps")] + ["-c", os.path.join(HERE, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
+def build_ab(verbose: bool = True) -> str:
+    """The diagnostic build with the A/B environment switches compiled in (-DCA_AB_SWITCHES): tools/ab/switches/libca.so,
+    loaded through CA_LIB_PATH by tools/env_ab.py, tools/attn_peaky.py, tools/gemm_group_m.py, tools/ln_rows_ab.py.  The
+    product library (libconceptattn.so) has none of these switches."""
+    return build(verbose=verbose, defines=["CA_AB_SWITCHES"], out=AB_LIB)
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--ab" in sys.argv:
+        print(build_ab())
+    else:
+        build(force="--force" in sys.argv)

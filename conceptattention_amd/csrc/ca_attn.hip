@@ -390,21 +390,21 @@ static int ca_attn_fwd_impl(const ca_attn_problem *problems, int32_t n_problems,
     return CA_ERR_ARG;
   }
   const bool pre = scale == CA_ATTN_Q_PRESCALED;
-  // Default: 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: ~250 us for
-  // 4352x4352x24 heads on MI355X.  A/B aid (same numerics): CA_ATTN_WAVES=4 = 128-row workgroups.
-  static const int nw = (getenv("CA_ATTN_WAVES") && atoi(getenv("CA_ATTN_WAVES")) == 4) ? 4 : 8;
+  // 8-wave workgroups (256 query rows, one per CU), K/V tiles by LDS-DMA: ~250 us for 4352x4352x24 heads on MI355X.
+  // (The 128-row, 4-wave form of rounds 1-4 -- slower, and its pre-scaled instantiation spilled -- is gone.)
+  constexpr int nw = 8;
   // pre-scaled q (the model path): the one-wave-per-SIMD kernel (ca_attn4.hip; 4 waves x 64 rows = 256 rows per workgroup
-  // as well, same numerics contract).  A/B aid: CA_ATTN_KERNEL=8 sends pre-scaled q through the two-waves-per-SIMD
-  // kernel below, which also serves every call that passes a scale.
-  static const bool want4 = !(getenv("CA_ATTN_KERNEL") && atoi(getenv("CA_ATTN_KERNEL")) == 8);
+  // as well, same numerics contract).  Every call that passes a scale runs on the two-waves-per-SIMD kernel below
+  // (diagnostic builds: CA_ATTN_KERNEL=8 sends pre-scaled q there too).
+  static const bool want4 = ca_ab_env("CA_ATTN_KERNEL", 4) != 8;
   const bool use4 = (pre && want4) || qk_f16;   // (half-precision q / k exist in the one-wave-per-SIMD kernel only)
   const int qrows = use4 ? 256 : nw * 32;
   AttnLaunch L = {};
   L.num_heads = num_heads;
   L.n_problems = n_problems;
   L.scale_log2 = scale * 1.4426950408889634f;
-  static const bool no_reref = getenv("CA_ATTN_REREF") && atoi(getenv("CA_ATTN_REREF")) == 0;
-  static const bool limit60 = getenv("CA_ATTN_LIMIT60") && atoi(getenv("CA_ATTN_LIMIT60")) == 1;
+  static const bool no_reref = ca_ab_env("CA_ATTN_REREF", 1) == 0;      // (diagnostic builds: tools/attn_peaky.py)
+  static const bool limit60 = ca_ab_env("CA_ATTN_LIMIT60", 0) == 1;
   L.flags = (no_reref ? 1 : 0) | (limit60 ? 2 : 0);
   const int hx = (num_heads + 7) / 8;  // heads per XCD group
   int total = 0;
@@ -460,8 +460,7 @@ static int ca_attn_fwd_impl(const ca_attn_problem *problems, int32_t n_problems,
   const unsigned long long dev_bit = ca_device_bit();
   if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipSuccess;
-    for (const void *fn : {(const void *)ca_attn_kernel<8>, (const void *)ca_attn_kernel<4>,
-                           (const void *)ca_attn_kernel<8, true>, (const void *)ca_attn_kernel<4, true>})
+    for (const void *fn : {(const void *)ca_attn_kernel<8>, (const void *)ca_attn_kernel<8, true>})
       if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
     if (e != hipSuccess) {
       ca_set_error("ca_attn_fwd_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -469,14 +468,10 @@ static int ca_attn_fwd_impl(const ca_attn_problem *problems, int32_t n_problems,
     }
     attr_done.fetch_or(dev_bit, std::memory_order_release);  // idempotent: a race only repeats the call
   }
-  if (nw == 8 && pre)
+  if (pre)
     hipLaunchKernelGGL((ca_attn_kernel<8, true>), dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
-  else if (nw == 8)
-    hipLaunchKernelGGL((ca_attn_kernel<8, false>), dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
-  else if (pre)
-    hipLaunchKernelGGL((ca_attn_kernel<4, true>), dim3(total), dim3(256), ATTN_LDS, (hipStream_t)stream, L);
   else
-    hipLaunchKernelGGL((ca_attn_kernel<4, false>), dim3(total), dim3(256), ATTN_LDS, (hipStream_t)stream, L);
+    hipLaunchKernelGGL((ca_attn_kernel<8, false>), dim3(total), dim3(512), ATTN_LDS, (hipStream_t)stream, L);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ca_set_error("ca_attn_fwd_bf16: launch failed: %s", hipGetErrorString(e));

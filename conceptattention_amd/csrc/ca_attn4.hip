@@ -125,7 +125,7 @@ int ca_attn4_launch(const AttnLaunch &L, int total, bool qk_f16, hipStream_t str
   }
   // more units than CUs: one workgroup per CU walks them (no workgroup dispatch between units; CA_ATTN_PERSIST=0: one
   // workgroup per unit, round 3's launch)
-  static const bool persist = !(getenv("CA_ATTN_PERSIST") && atoi(getenv("CA_ATTN_PERSIST")) == 0);
+  static const bool persist = ca_ab_env("CA_ATTN_PERSIST", 1) != 0;
   const int n_cu = ca_cu_count();
   AttnLaunch LL = L;
   LL.total_units = total;

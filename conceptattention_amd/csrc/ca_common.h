@@ -101,6 +101,19 @@ inline unsigned long long ca_device_bit() {
   return 1ull << (dev & 63);
 }
 
+// A/B switches read from the environment exist only in diagnostic builds (-DCA_AB_SWITCHES:
+// `python -m conceptattention_amd.csrc.build --ab` -> tools/ab/switches/libca.so, used through CA_LIB_PATH by the tools
+// under tools/); the product library reads no environment variable and always takes the default.
+#ifdef CA_AB_SWITCHES
+#include <stdlib.h>
+inline int ca_ab_env(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#else
+inline int ca_ab_env(const char *, int dflt) { return dflt; }
+#endif
+
 // host-side plumbing (ca_api.hip): error text; CU count of the current device (cached; -1 if the query fails)
 void ca_set_error(const char *fmt, ...);
 int ca_cu_count();

@@ -46,15 +46,7 @@ struct GemmLaunch {
   // thin-row kernel (a thin last row tile under the 256x256 bf16 ping-pong tile): 32 x 128 tiles
   int32_t thin_row0[CA_GEMM_MAX_PROBLEMS];   // first row of the problem's thin part
   int32_t thin_nt[CA_GEMM_MAX_PROBLEMS];     // its 128-column tiles (N / 128), 0 = none
-  int32_t queue_slot;     // persistent walk: -1 = fixed stride of the grid; else the row of ca_gemm_queue the workgroups
-                          // of an XCD draw their next tile from (experiment, round 5: CA_GEMM_QUEUE=1)
 };
-
-// Dynamic tile queue of the persistent walk (experiment): per launch one row of counters, [0..7] = tiles handed out per
-// XCD class beyond each workgroup's first, [8] = workgroups that have left; the last one to leave zeroes the row, so a
-// row is ready again when its launch has ended (rows are dealt round-robin by the host: 256 launches may be in flight).
-constexpr int CA_GEMM_QSLOTS = 256;
-__device__ unsigned int ca_gemm_queue[CA_GEMM_QSLOTS][16];
 
 // A last row tile with at most this many valid rows is "thin": its MFMAs on row fragments past M are skipped (the
 // K loop is then paced by the staging and the barriers, about half a tile time), and it is walked last so that it
@@ -1012,31 +1004,7 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
 template <int NL, int NHI, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) {
   extern __shared__ __attribute__((aligned(128))) char smem[];
-  if (L.persist_tiles > 0 && L.queue_slot >= 0) {
-    // dynamic walk: a workgroup's tiles keep its XCD class (tile v = 8 k + x on XCD x, as with the fixed stride), but
-    // the k-th tile of a class goes to whichever of the XCD's workgroups asks first.  The request for the NEXT tile is
-    // issued before this tile starts and read after it (no exposed round trip); s_next is double-buffered by parity.
-    __shared__ int s_next[2];
-    unsigned int *q = ca_gemm_queue[L.queue_slot];
-    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
-    int v = blockIdx.x, par = 0;
-    while (v < L.persist_tiles) {
-      unsigned int nxt = 0;
-      if (threadIdx.x == 0) nxt = atomicAdd(&q[xcd], 1u);
-      ca_gemm_pp_tile<NL, NHI, FP8>(L, smem, v, L.persist_tiles);
-      if (threadIdx.x == 0) s_next[par] = (int)(nxt + (unsigned)per) * 8 + xcd;
-      __syncthreads();
-      v = s_next[par];
-      par ^= 1;
-    }
-    if (threadIdx.x == 0) {
-      __threadfence();
-      if (atomicAdd(&q[8], 1u) == gridDim.x - 1) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) atomicExch(&q[i], 0u);
-      }
-    }
-  } else if (L.persist_tiles > 0) {
+  if (L.persist_tiles > 0) {
     for (int v = blockIdx.x; v < L.persist_tiles; v += gridDim.x) {
       ca_gemm_pp_tile<NL, NHI, FP8>(L, smem, v, L.persist_tiles);
       __syncthreads();
@@ -1389,10 +1357,7 @@ int tile_n_of(int tile) {
 // forward (17 row tiles) the choice matters less than 1 %, except that the N = 3072 launches prefer 2-4 to 1.
 // CA_GEMM_GROUP_M overrides (A/B aid).  The order of the tiles changes nothing about any tile's result.
 int pick_group_m(int nt, int mt, bool interleave) {
-  static const int env = [] {
-    const char *e = getenv("CA_GEMM_GROUP_M");
-    return e ? atoi(e) : 0;
-  }();
+  static const int env = ca_ab_env("CA_GEMM_GROUP_M", 0);
   if (env > 0) return env;
   // (with the XCDs sharing each run of 256 tiles the choice is flat over 4 .. 8; one item per forward -- 17 row tiles --
   // prefers 4 for the widest launch: linear1 414 vs 423 us)
@@ -1406,12 +1371,12 @@ int pick_group_m(int nt, int mt, bool interleave) {
 // round) instead of getting the thin-row kernel's own launch?  ONE predicate for the tile chooser and for gemm_impl
 // (CA_GEMM_THIN_INWALK=0: never; round 3's behaviour, A/B aid).
 bool thin_rides_in_walk(long main_all, long thin_all, int n_cu) {
-  static const int inwalk_env = [] { const char *e = getenv("CA_GEMM_THIN_INWALK"); return e ? atoi(e) : 1; }();
+  static const int inwalk_env = ca_ab_env("CA_GEMM_THIN_INWALK", 1);
   return inwalk_env && n_cu > 0 && thin_all > 0 && main_all % n_cu != 0 && main_all % n_cu + thin_all <= n_cu;
 }
 
 bool thin_kernel_enabled() {   // CA_GEMM_THIN_KERNEL=0: thin rows stay 256-column tiles of the ping-pong walk (A/B aid)
-  static const int env = [] { const char *e = getenv("CA_GEMM_THIN_KERNEL"); return e ? atoi(e) : 1; }();
+  static const int env = ca_ab_env("CA_GEMM_THIN_KERNEL", 1);
   return env != 0;
 }
 
@@ -1602,7 +1567,7 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
   // the 8 XCDs share each run of 256 consecutive tiles of the order (XCD x: its tiles 32 x .. 32 x + 31) instead of
   // owning one eighth of the order each: all of them stream the same group of A rows at a time (CA_GEMM_XCD_INTERLEAVE=0:
   // rounds 1-3's contiguous ranges)
-  static const int xil_env = [] { const char *e = getenv("CA_GEMM_XCD_INTERLEAVE"); return e ? atoi(e) : 1; }();
+  static const int xil_env = ca_ab_env("CA_GEMM_XCD_INTERLEAVE", 1);
   const int n_cu = ca_cu_count();
   // (the order's "round" is 256 tiles = 32 per XCD, which is what runs together only on a 256-CU part: elsewhere the
   // contiguous ranges, whose mapping does not assume a grid size)
@@ -1641,18 +1606,11 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
   if (pp_tile) total = total_pp;  // (the simple kernel keeps every row tile)
   hipStream_t s = (hipStream_t)stream;
   {  // persistent walk of the tiles when there is more than one round of them (CA_GEMM_PERSIST=0 disables)
-    static const int persist_env = [] {
-      const char *e = getenv("CA_GEMM_PERSIST");
-      return e ? atoi(e) : 1;
-    }();
+    static const int persist_env = ca_ab_env("CA_GEMM_PERSIST", 1);
     const int n = n_cu;
-    L.queue_slot = -1;
     if (persist_env && n > 0 && n % 8 == 0 && total > n) {
       L.persist_tiles = total;
       L.persist_tiles_grid = n;
-      static const int queue_env = [] { const char *e = getenv("CA_GEMM_QUEUE"); return e ? atoi(e) : 0; }();
-      static std::atomic<unsigned> next_slot{0};
-      if (queue_env) L.queue_slot = (int)(next_slot.fetch_add(1, std::memory_order_relaxed) % CA_GEMM_QSLOTS);
     }
   }
   if (fp8) return launch_pp<2, 2, true>(L, total, s);

@@ -886,7 +886,7 @@ int ln_modulate_impl(const char *FN, const void *x, int32_t ldx, void *out, int3
   }
   const dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
-  static const bool rows_kernel = !(getenv("CA_LN_ROWS") && atoi(getenv("CA_LN_ROWS")) == 0);
+  static const bool rows_kernel = ca_ab_env("CA_LN_ROWS", 1) != 0;
   if (rows_kernel && x_f32 && !fp8 && H == 3072) {   // the model's shape: a wave walks 8 rows (vectors kept in registers)
     const int waves = (M + LN_ROWS_PER_WAVE - 1) / LN_ROWS_PER_WAVE;
     const dim3 g2((waves + 3) / 4);

@@ -202,12 +202,13 @@ class HipFluxDiT:
         # values (pinned by tests/golden/timestep_embedding_bf16.npz).
         self.bf16_timesteps = bool(bf16_timesteps)
         # adaLN modulations of MANY conditioning vectors (all steps x items, precompute_conditioning) as two bf16 MFMA
-        # GEMMs instead of one weight-streaming GEMV pass per 4 vectors (_modulation_rows); False = GEMV only (A/B)
-        self.modulation_by_gemm = os.environ.get("CA_MODULATION_GEMM", "1") != "0"
+        # GEMMs instead of one weight-streaming GEMV pass per 4 vectors (_modulation_rows); False = GEMV only (A/B aid:
+        # set the attribute; round 5 retired the CA_MODULATION_GEMM / CA_ATTN_PRESCALE / CA_SPLIT_Q_CAPTURE variables)
+        self.modulation_by_gemm = True
         # softmax_scale * log2(e) folded into q by the qkv epilogue (in fp32, before q's one rounding to bf16), so the
-        # attention kernel's probability is a bare exp2 (include/conceptattn.h CA_ATTN_Q_PRESCALED); "0" = the kernel
+        # attention kernel's probability is a bare exp2 (include/conceptattn.h CA_ATTN_Q_PRESCALED); False = the kernel
         # multiplies every score instead (A/B aid)
-        self.prescale_q = os.environ.get("CA_ATTN_PRESCALE", "1") != "0"
+        self.prescale_q = True
         # sampling.denoise keeps the latent in fp32 between the Euler steps when the model says so (A/B: CA_FP32_LATENT=0)
         self.fp32_latent = os.environ.get("CA_FP32_LATENT", "1") != "0"
         # An fp32 copy of the captured layers' [text | image] attention rows for the output-space logits (round 3).
@@ -222,8 +223,8 @@ class HipFluxDiT:
         # (tests/tools/error_budget.py: 3.3e-3 -> 3.5e-4 per map).  The LayerNorm writes a second bf16 plane with what
         # the rounding drops, one more GEMM applies the q weights to it (image rows and concept rows of the captured
         # layers only: +0.45 % FLOPs per call), and ops.qpre_finish normalises the sum.  The q the ATTENTION uses is
-        # untouched, so the image does not depend on which layers are captured.  "0" = one rounding more (A/B aid).
-        self.split_q_capture = os.environ.get("CA_SPLIT_Q_CAPTURE", "1") != "0"
+        # untouched, so the image does not depend on which layers are captured.  False = one rounding more (A/B aid).
+        self.split_q_capture = True
         # The rotated q and k of the attention as IEEE half instead of bf16 (ca_gemm_problem.qk_f16 ->
         # ca_attn_fwd_qk16): their bf16 rounding is one of the two things that bound a single output-space heat map
         # (round 4, tests/tools/error_budget.py --out-space2: 9e-4 -> 2.5e-4 per map with 11-bit q / k; v and the
@@ -232,11 +233,23 @@ class HipFluxDiT:
         # below); the chip clocks the f16 MFMA 1.6 % lower than the bf16 one, and with every block in half precision
         # ("all") the maps are no closer to the oracle (profiles/r04_full_depth_parity*.json: 5.6e-4 / 9.6e-4 worst single
         # map against 5.7e-4 / 8.4e-4) at -0.6 % heat maps/s.  "0": bf16 everywhere, as the reference (A/B aid).
-        # Needs the pre-scaled-q kernel (CA_ATTN_PRESCALE=0 / CA_ATTN_KERNEL=8 switch it off).
+        # Needs the pre-scaled-q kernel (prescale_q = False switches it off: _qk16).
         self.qk_f16 = os.environ.get("CA_QK_F16", "captured")
         # the ATTENTION's q of the captured layers' image / concept rows from the unrounded LayerNorm output as well
         # (ops.qpre_finish writes it over the epilogue's; _double_block); "0" = round 3's q (A/B aid)
         self.split_q_attention = os.environ.get("CA_SPLIT_Q_ATTENTION", "1") != "0"
+        # Exact independence of everything the forward returns from WHICH layers' maps are requested (the reference's
+        # property: the concept stream and the capture are read-only side computations, modified_double_stream_block.py:
+        # 105-119, 185-191).  False (default): a captured layer's attention uses the accurate q for its image and concept
+        # rows and half-precision q / k, so the latent moves at rounding level with layer_indices (bounded:
+        # tests/test_full_depth_gpu.py::test_latent_dependence_on_the_captured_layer_set).  True: every layer's attention
+        # output that feeds proj / the residual streams is formed exactly as in an uncaptured layer (rounded-operand q,
+        # bf16 q / k), and the captured layers' maps come from SEPARATE attention problems of the same launch -- the
+        # accurate q of the image rows (and of the concept rows) against the same keys and values, written to scratch
+        # rows that only the heat maps read.  Cost: the image rows' attention twice in captured layers (+1.3 % of a
+        # generate call with 4 of 57 layers captured; +15 % of a 19-layer sweep forward); single output-space maps then
+        # carry k's bf16 rounding again (measured in the same test file).
+        self.capture_independent_image = False
         # fp8 mode: the qkv projection of a layer whose maps are requested stays bf16 (_double_block)
         self.fp8_bf16_qkv_when_captured = os.environ.get("CA_FP8_QKV_BF16_CAPTURED", "1") != "0"
         # the heat-map updates of a captured layer (all work items, both spaces) as ONE ca_heatmap_fused launch; False =
@@ -244,8 +257,6 @@ class HipFluxDiT:
         self.fused_heatmaps = True
         if self.qk_f16 not in ("all", "captured", "0"):
             raise ValueError("CA_QK_F16 must be all, captured or 0")
-        if not self.prescale_q or os.environ.get("CA_ATTN_KERNEL") == "8":
-            self.qk_f16 = "0"
         self.set_precision(precision)
 
     # ---- reduced-precision mode (BASELINE.json configs[4]; no counterpart in the reference)
@@ -340,6 +351,10 @@ class HipFluxDiT:
         "XML": lambda n, B, T, L, H: ((n, H), torch.bfloat16),       # low plane of XM: bf16(y - float(bf16(y)))
         "QD": lambda n, B, T, L, H: ((n, H), torch.float32),         # its q projection (ops.qpre_finish adds it)
         "ATTI32": lambda n, B, T, L, H: ((B, T + L, H), torch.float32),   # fp32 [text | image] attention rows
+        # capture_independent_image: the accurate q of the captured layers' image / concept rows (the map-side attention
+        # problems' queries) and those problems' bf16 output rows, which nothing but the heat maps reads
+        "QACC": lambda n, B, T, L, H: ((n, H), torch.bfloat16),
+        "ATTM": lambda n, B, T, L, H: ((n, H), torch.bfloat16),
     }
 
     def _lazy_buffer(self, name: str) -> torch.Tensor:
@@ -355,6 +370,8 @@ class HipFluxDiT:
     XML = property(lambda self: self._lazy_buffer("XML"))
     QD = property(lambda self: self._lazy_buffer("QD"))
     ATTI32 = property(lambda self: self._lazy_buffer("ATTI32"))
+    QACC = property(lambda self: self._lazy_buffer("QACC"))
+    ATTM = property(lambda self: self._lazy_buffer("ATTM"))
 
     def clear_workspaces(self) -> None:
         """Drop every cached activation set (up to WS_CACHE_ENTRIES sets stay resident between calls: ~1.6 GB per work
@@ -643,7 +660,7 @@ class HipFluxDiT:
         return g
 
     def _qk16(self, capture: bool) -> bool:
-        return self.qk_f16 == "all" or (self.qk_f16 == "captured" and bool(capture))
+        return self.prescale_q and (self.qk_f16 == "all" or (self.qk_f16 == "captured" and bool(capture)))
 
     def _q_out_scale(self) -> float:
         """What the qkv epilogue multiplies the rotated q by: softmax_scale * log2(e) (head_dim 128), or 0 (= 1)."""
@@ -697,7 +714,10 @@ class HipFluxDiT:
         # K5+K6+K7: qkv projections (image stream + [concept|text] stream in one grouped launch) with
         # QK-RMSNorm and RoPE fused into the epilogue; pre-RoPE q kept for the cross-attention maps
         qpre = self.QPRE if capture else None
-        qk16 = self._qk16(capture)
+        # (capture_independent_image: q / k exactly as in an uncaptured layer; the accurate q goes to QACC instead)
+        indep = bool(split and self.capture_independent_image and self.split_q_attention)
+        qk16 = self._qk16(capture and not self.capture_independent_image)
+        self._layer_indep = indep
         if split:   # q weights applied to the low plane: image rows and the concept rows (text rows are not captured)
             # (256 x 256 tiles named: the automatic choice prices the concept rows' problem and lands on 256 x 128,
             # 376 vs 332 us per 5-item launch)
@@ -722,29 +742,46 @@ class HipFluxDiT:
             # (the operand's rounding reaches the map through q; tests/tools/diag_out_space.py).  The image therefore
             # depends, at rounding level, on which layers' maps are requested; CA_SPLIT_Q_ATTENTION=0 restores q.
             sq = dict(q_out_scale=self._q_out_scale(), q_f16=qk16) if self.split_q_attention else {}
+            q_acc = self.QACC if indep else qs
             ops.qpre_finish(qpre[oI:], self.QD[oI:], W[b + "img_attn.norm.query_norm.scale"], NH,
-                            **(dict(rope=self.ROPE[oI:], q_out=qs[oI:], **sq) if sq else {}))
+                            **(dict(rope=self.ROPE[oI:], q_out=q_acc[oI:], **sq) if sq else {}))
             ops.qpre_finish(qpre[:oT], self.QD[:oT], W[b + "txt_attn.norm.query_norm.scale"], NH,
-                            **(dict(rope=self.ROPE[:oT], q_out=qs[:oT], **sq) if sq else {}))
+                            **(dict(rope=self.ROPE[:oT], q_out=q_acc[:oT], **sq) if sq else {}))
         # K8+K9: per item, joint text+image attention and the concept rows; one launch (concept problems first)
+        f32img = self._f32_image_vectors(capture, heatmaps)
+
+        def concept_problem(j, q_rows, out_rows, out32):
+            cj, ij = slice(j * C, (j + 1) * C), slice(oI + j * Li, oI + (j + 1) * Li)
+            if cross and self_:
+                return ops.Attn(q_rows[cj], out_rows[cj], ks[cj], vs[cj], ks[ij], vs[ij], out_f32=out32)
+            if cross:   # :129-138 image keys/values only
+                return ops.Attn(q_rows[cj], out_rows[cj], ks[ij], vs[ij], out_f32=out32)
+            return ops.Attn(q_rows[cj], out_rows[cj], ks[cj], vs[cj], out_f32=out32)   # :139-147 concept keys/values only
         probs = []
-        for j in range(B):
-            cj, tj, ij = slice(j * C, (j + 1) * C), slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)
-            if C > 0:
-                if cross and self_:
-                    probs.append(ops.Attn(qs[cj], ATT[cj], ks[cj], vs[cj], ks[ij], vs[ij], out_f32=self.ATT32[cj]))
-                elif cross:   # :129-138 image keys/values only
-                    probs.append(ops.Attn(qs[cj], ATT[cj], ks[ij], vs[ij], out_f32=self.ATT32[cj]))
-                elif self_:   # :139-147 concept keys/values only
-                    probs.append(ops.Attn(qs[cj], ATT[cj], ks[cj], vs[cj], out_f32=self.ATT32[cj]))
+        if C > 0 and (cross or self_):
+            for j in range(B):   # (independent mode: the rounded-q rows feed proj; the fp32 rows of the maps come below)
+                probs.append(concept_problem(j, qs, ATT, None if indep else self.ATT32[j * C:(j + 1) * C]))
         if C > 0 and not (cross or self_):   # :157-159 concept_attn = concept_v
             ATT[:oT].copy_(vs[:oT])
             self.ATT32[:oT].copy_(vs[:oT])
         for j in range(B):
             tj, ij = slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)
             probs.append(ops.Attn(qs[tj], ATT[tj], ks[tj], vs[tj], ks[ij], vs[ij], q1=qs[ij], out1=ATT[ij],
-                                  out_f32=self.ATTI32[j] if self._f32_image_vectors(capture, heatmaps) else None))
-        ops.attention(probs, NH, q_prescaled=self.prescale_q, qk_f16=qk16)
+                                  out_f32=self.ATTI32[j] if (f32img and not indep) else None))
+        if indep:
+            # the maps' side: the accurate q of the image rows against the same keys / values, into rows that only the
+            # heat maps read (one more problem per item in this launch) ...
+            for j in range(B):
+                tj, ij = slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)
+                probs.append(ops.Attn(self.QACC[ij], self.ATTM[ij], ks[tj], vs[tj], ks[ij], vs[ij],
+                                      out_f32=self.ATTI32[j, T:] if f32img else None))
+        ops.attention(probs[:L.ATTN_MAX_PROBLEMS], NH, q_prescaled=self.prescale_q, qk_f16=qk16)
+        if len(probs) > L.ATTN_MAX_PROBLEMS:
+            ops.attention(probs[L.ATTN_MAX_PROBLEMS:], NH, q_prescaled=self.prescale_q, qk_f16=qk16)
+        if indep and C > 0 and (cross or self_):
+            # ... and of the concept rows (B tiny problems: their own launch, the first one is full at 5 items)
+            ops.attention([concept_problem(j, self.QACC, self.ATTM, self.ATT32[j * C:(j + 1) * C]) for j in range(B)],
+                          NH, q_prescaled=self.prescale_q, qk_f16=qk16)
         if capture:
             self._capture(out, i, g, NH, return_vectors, heatmaps)
         if fp8:
@@ -830,7 +867,8 @@ class HipFluxDiT:
             # is the dominant heat-map error otherwise -- DESIGN.md "tolerance")
             li = hm.layer_indices.index(layer)
             cj, ij = slice(j * C, (j + 1) * C), slice(oI + j * Li, oI + (j + 1) * Li)
-            img_out = self.ATTI32[j, g.T:] if self._f32_image_vectors(True, heatmaps) else ATT[ij]
+            img_out = self.ATTI32[j, g.T:] if self._f32_image_vectors(True, heatmaps) else \
+                (self.ATTM[ij] if self._layer_indep else ATT[ij])   # (_layer_indep: set by _double_block for this layer)
             for img_vec, con_vec, acc, table in ((img_out, self.ATT32[cj], hm.out_space, hm.per_layer_out),
                                                  (QPRE[ij], QPRE[cj], hm.cross_space, hm.per_layer_cross)):
                 if acc is None and table is None:

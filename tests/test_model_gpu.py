@@ -235,12 +235,12 @@ def test_full_size_double_block_vs_reference_golden(golden):
 
 PEAKY_MEASURED = {}
 # max-abs vs the reference's fp32 block, <= 1.5 x measured on MI355X (profiles/r05_peaky_block_parity.json; the worse of
-# the two q / k storage types); the reference's own bf16 run: iid8 2.3e-2 / 8.6e-3 / 1.4e-2 / 3.9e-2 / 2.9e-2,
-# coldtext 8.4e-3 / 4.7e-3 / 5.2e-3 / 2.1e-2 / 3.0e-2
-PEAKY_BOUNDS = {"iid8": {"heatmap_out": 2.3e-2, "heatmap_cross": 1e-3, "concept_attn_f32": 1.5e-2, "img_attn_rows": 4e-2,
-                         "img_out_rows": 3e-2},
-                "coldtext": {"heatmap_out": 8.5e-3, "heatmap_cross": 1e-3, "concept_attn_f32": 5.2e-3,
-                             "img_attn_rows": 2.1e-2, "img_out_rows": 3e-2}}
+# the two q / k storage types: half precision / bf16).  Measured, output-space map: iid8 6.3e-3 / 8.8e-3, coldtext
+# 1.9e-3 / 3.1e-3; cross-space map 5e-6; the reference's own bf16 run: iid8 2.3e-2 / 8.6e-3 (cross), coldtext 8.4e-3 / 4.7e-3.
+PEAKY_BOUNDS = {"iid8": {"heatmap_out": 1.32e-2, "heatmap_cross": 1e-4, "concept_attn_f32": 9.6e-3, "img_attn_rows": 1.8e-2,
+                         "img_out_rows": 2.5e-3},
+                "coldtext": {"heatmap_out": 4.7e-3, "heatmap_cross": 1e-4, "concept_attn_f32": 4.9e-3,
+                             "img_attn_rows": 1.31e-2, "img_out_rows": 1.9e-3}}
 
 
 @pytest.mark.parametrize("qk_f16", ["captured", "0"])

@@ -14,6 +14,10 @@ workgroup a full classical recomputation).
 import json
 import math
 import os
+# the switches this tool flips exist in the diagnostic build only: python -m conceptattention_amd.csrc.build --ab
+_AB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ab", "switches", "libca.so")
+if os.path.exists(_AB):
+    os.environ.setdefault("CA_LIB_PATH", _AB)
 import subprocess
 import sys
 

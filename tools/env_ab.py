@@ -1,5 +1,6 @@
 """Same-box A/B of whole-path throughput between ENVIRONMENT settings of one build: runs bench.py in fresh processes,
 alternating (devices of this pool differ by several per cent, so only same-box pairs compare).
+(library switches need the diagnostic build: python -m conceptattention_amd.csrc.build --ab, picked up automatically)
 usage: python tools/env_ab.py [--reps 3] [--bench "--batch 1 --steps 4"] "CA_X=0" "CA_X=1" ...  ("" = default env)"""
 import json
 import os
@@ -7,6 +8,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the library's A/B switches exist in the diagnostic build only (python -m conceptattention_amd.csrc.build --ab)
+AB_LIB = os.path.join(ROOT, "tools", "ab", "switches", "libca.so")
 args = sys.argv[1:]
 reps, bench_args = 3, ["--steps", "10", "--warmup", "1"]
 while args and args[0] in ("--reps", "--bench"):
@@ -17,6 +20,8 @@ while args and args[0] in ("--reps", "--bench"):
 for rep in range(reps):
     for setting in args:
         env = dict(os.environ)
+        if os.path.exists(AB_LIB):
+            env.setdefault("CA_LIB_PATH", AB_LIB)
         for kv in setting.split():
             k, v = kv.split("=", 1)
             env[k] = v

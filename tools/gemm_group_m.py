@@ -5,6 +5,10 @@ override is read once) and with the library's own choice ("auto").  Best of 3 x 
     python tools/gemm_group_m.py            -> table on stdout (profiles/r04_gemm_group_m.txt)
 """
 import os
+# the switches this tool flips exist in the diagnostic build only: python -m conceptattention_amd.csrc.build --ab
+_AB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ab", "switches", "libca.so")
+if os.path.exists(_AB):
+    os.environ.setdefault("CA_LIB_PATH", _AB)
 import subprocess
 import sys
 

@@ -1,6 +1,10 @@
 """A/B of the two LayerNorm + modulation kernels on the model's 5-item launch: time and bit equality.
 usage: python tools/ln_rows_ab.py   (runs itself twice: CA_LN_ROWS=0 / 1)"""
 import os, subprocess, sys
+# the switches this tool flips exist in the diagnostic build only: python -m conceptattention_amd.csrc.build --ab
+_AB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ab", "switches", "libca.so")
+if os.path.exists(_AB):
+    os.environ.setdefault("CA_LIB_PATH", _AB)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if "CA_LN_ROWS" not in os.environ:
     for v in ("0", "1", "0", "1"):
