@@ -280,7 +280,11 @@ def main():
         return run_many([j], 1, 1)[0]
 
     if warm_items:
-        run_many(warm_items, args.streams, args.batch)
+        # (encode / sweep: a group is one ~0.1 s forward; the chip needs a few of them after the idle seconds of weight
+        # and input set-up before its clocks are where a sustained run holds them -- a timed region that starts on the
+        # second forward after idle measured 110-150 ms per forward for the same 106 ms of kernels, round 5)
+        for _ in range(1 if wl == "generate" else 5):
+            run_many(warm_items, args.streams, args.batch)
         # a ragged group (steps not a multiple of --batch) is a forward of another shape: build its activation set
         # and kernels before the timed region as well (HipFluxDiT keeps the few most recent activation sets)
         for n_r in sorted({len(timed_items) % args.batch, len(timed_items[:-min(args.batch, len(timed_items))])
@@ -518,28 +522,35 @@ def main():
         # under profiles/ (method and the gfx950 x2 FETCH_SIZE correction are recorded in the file)
         try:
             import glob
-            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]
-            pmc_doc = json.load(open(pmc_file))
-            pmc = pmc_doc["kernels"]
-            # a per-launch average is only this launch's traffic if every profiled launch had the timed shape:
-            # the file states its launch mix (tools/profile_round.py) and one of another mix is refused
-            mix = pmc_doc.get("launch_mix") or {}
-            same_mix = (mix.get("items_per_forward") == args.batch and mix.get("workload") == wl
+            # a per-launch average is only this launch's traffic if every profiled launch had the timed shape: every
+            # file states its launch mix (tools/profile_round.py); the newest one of THIS run's mix is used, none otherwise
+            pmc_doc = pmc_file = None
+            seen = []
+            for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+                doc = json.load(open(cand))
+                mix = doc.get("launch_mix") or {}
+                seen.append(os.path.basename(cand))
+                if (mix.get("items_per_forward") == args.batch and mix.get("workload") == wl
                         and mix.get("model") == args.model and mix.get("concepts") == C
-                        and mix.get("size") == args.size and mix.get("only_batched_launches") is True)
-            key = roof.get("kernel", "").split(" ")[0]
-            if not same_mix:
-                roof["traffic_source"] = (f"profiles/{os.path.basename(pmc_file)} holds launch_mix {mix or 'none'}, not "
-                                          "this run's shape: traffic not reported")
-            elif key in pmc and not fp8:
-                roof["traffic"] = pmc[key]["bytes_per_launch"]
-                roof["traffic_source"] = (f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                          f"passes of `{pmc_doc.get('command', 'bench.py --profile-mode')}` at "
-                                          f"{pmc_doc.get('git_head', 'an earlier commit')}: every launch of that process is a "
-                                          f"{args.batch}-item launch; counters cannot be read from inside the process)")
-            akey = roof_attn["kernel"].split(" ")[0] if roof_attn is not None else None
-            if same_mix and akey in pmc and not fp8:
-                roof_attn["traffic"] = pmc[akey]["bytes_per_launch"]
+                        and mix.get("size") == args.size and mix.get("only_batched_launches") is True
+                        and mix.get("precision", "bf16") == args.precision):
+                    pmc_doc, pmc_file = doc, cand
+                    break
+            if pmc_doc is None:
+                roof["traffic_source"] = (f"no profiles/r*_pmc_hbm_traffic.json holds this run's launch mix (looked at "
+                                          f"{seen[:4]}): traffic not reported")
+            else:
+                pmc = pmc_doc["kernels"]
+                key = roof.get("kernel", "").split(" ")[0]
+                if key in pmc and not fp8:
+                    roof["traffic"] = pmc[key]["bytes_per_launch"]
+                    roof["traffic_source"] = (f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                              f"passes of `{pmc_doc.get('command', 'bench.py --profile-mode')}` at "
+                                              f"{pmc_doc.get('git_head', 'an earlier commit')}: every launch of that process is a "
+                                              f"{args.batch}-item launch; counters cannot be read from inside the process)")
+                akey = roof_attn["kernel"].split(" ")[0] if roof_attn is not None else None
+                if akey in pmc and not fp8:
+                    roof_attn["traffic"] = pmc[akey]["bytes_per_launch"]
         except (OSError, KeyError, ValueError, IndexError):
             pass
         roof["frac"] = roof["achieved"] / roof["peak"]

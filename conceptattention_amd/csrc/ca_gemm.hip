@@ -714,6 +714,9 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
     if (epi == CA_EPI_QKV_NORM_ROPE && n0 < (P.n_split / 3) * 2) {
       const int hd = P.n_split / 3;               // heads * 128
       const bool is_q = n0 < hd;
+      // (launch-uniform; bf16 operands only: the low-plane projection never runs in e4m3, and the fp8 instantiation
+      // has no registers for it -- gemm_impl rejects the combination)
+      const bool add_q = !FP8 && is_q && P.q_prerope && P.qpre_f32 == 3;
       const bf16 *nscale = (const bf16 *)(is_q ? P.norm_q : P.norm_k);
       float *part = (float *)smem;                // [2 halves][256 rows][4 column-waves]
       float x[8][2][8];
@@ -744,6 +747,24 @@ __device__ __forceinline__ void ca_gemm_pp_tile(const GemmLaunch &L, char *smem,
         }
         s8 = *(const bf16x8 *)(nscale + cih);
       };
+      if (add_q) {
+        // qpre_f32 = 3: the hi plane's raw projection, left in q_prerope by the main qkv launch, joins the accumulators
+        // ((acc + raw) + bias in both kernels) -- before the RoPE values are fetched: their 64 registers and these 8 do
+        // not fit beside the 128 accumulators
+#pragma unroll
+        for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+          for (int mi = 0; mi < 8; ++mi) {
+            const int m = min(m0 + (mi >> 2) * 128 + wm * 64 + 16 * (mi & 3) + (lane & 15), M - 1);
+            const float *qp = (const float *)P.q_prerope + (size_t)m * P.ldp + n0 + hn * 128 + cih;
+            const f32x4 a0 = *(const f32x4 *)qp, a1 = *(const f32x4 *)(qp + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[mi][hn * 2][r] = acc[mi][hn * 2][r] + a0[r];
+              acc[mi][hn * 2 + 1][r] = acc[mi][hn * 2 + 1][r] + a1[r];
+            }
+          }
+      }
       if constexpr (!FP8) load_rope();   // (the fp8 instantiation has no registers for it here: behind the row sums)
       __syncthreads();  // every wave has retired its own LDS-DMA (vmcnt 0 above): the LDS is reusable
 #pragma unroll
@@ -1031,24 +1052,42 @@ __global__ __launch_bounds__(512, 2) void ca_gemm_pp_kernel(const GemmLaunch L) 
 // landed" followed by the barrier that publishes tile t: one barrier per K tile, three tiles in flight.
 // MF = 16-row fragments per workgroup: 2 (32 rows: the concept rows of a batch) or 4 (64 rows: longer thin parts and
 // the 2 x items x steps conditioning vectors of the modulation GEMM, so that the weights stream once per 64 rows)
-constexpr int THIN_N = 128, THIN_SLOTS = 4;
-template <int MF>
+// NW = waves per workgroup (round 5): 4 (128 columns = one head: the fused QK-norm + RoPE epilogue reduces a head's row
+// sums over its 4 column-waves) or 1 (32 columns, every other epilogue).  What bounds a thin launch is how many CUs
+// stream weight rows: with 128-column workgroups N = 3072 gave 24 of them -- 24 CUs each pulling 128 rows x K through
+// one vector L1 (mlp.2, K = 12288: 3.1 MB per CU) -- with 32-column workgroups it is 96.  Same fragments, same k order
+// per accumulator: a row's bits do not depend on NW.
+// A one-wave workgroup's K loop is a latency chain (wait for the tile staged SLOTS - 1 iterations ago, barrier, 8 MFMAs);
+// its LDS stage is small (8 / 12 KB), so its ring is deeper: 8 / 6 slots = 7 / 5 K tiles in flight (56 / 60 of the 63
+// loads a wave may have outstanding).  The four-wave form keeps 4 slots: 6 / 7 were measured and change nothing (its
+// launches -- the modulation GEMM's 8 126 workgroups at 4.6-5.6 TB/s -- are not short of bytes in flight;
+// tools/thin_ab.py, round 5).
+constexpr int THIN_N = 128;
+template <int MF, int NW>
 struct ThinCfg {
-  static constexpr int M = 16 * MF, STAGE = (M + THIN_N) * 128, LDS = THIN_SLOTS * STAGE;
-  static constexpr int PIECES = (M + THIN_N) / 8 / 4;  // 1 KB pieces per wave and K tile (5 or 6)
+  static constexpr int M = 16 * MF, N = 32 * NW, STAGE = (M + N) * 128;
+  static constexpr int PIECES = (M + N) / 8 / NW;  // 1 KB pieces per wave and K tile (NW = 4: 5 or 6; NW = 1: 8 or 12)
+  static constexpr int SLOTS = NW == 4 ? 4 : (MF == 2 ? 8 : 6);
+  static constexpr int LDS = SLOTS * STAGE;
+  static_assert(PIECES * (SLOTS - 1) <= 63, "vmcnt counts at most 63 outstanding loads");
 };
+template <int N>
+__device__ __forceinline__ void ca_wait_vmcnt_imm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-template <int MF>
-__global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
-  using TC = ThinCfg<MF>;
-  constexpr int THIN_M = TC::M, THIN_STAGE = TC::STAGE, NP = TC::PIECES;
+template <int MF, int NW>
+__global__ __launch_bounds__(64 * NW) void ca_gemm_thin_kernel(const GemmLaunch L) {
+  using TC = ThinCfg<MF, NW>;
+  constexpr int THIN_M = TC::M, THIN_STAGE = TC::STAGE, NP = TC::PIECES, THIN_N = TC::N, THIN_SLOTS = TC::SLOTS;
   extern __shared__ __attribute__((aligned(128))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = 32-column group
   int u = blockIdx.x;
-  const int prob = (u >= L.thin_nt[0]) ? 1 : 0;
-  if (prob) u -= L.thin_nt[0];
+  const int nt0 = L.thin_nt[0] * (4 / NW);   // (thin_nt counts 128-column tiles)
+  const int prob = (u >= nt0) ? 1 : 0;
+  if (prob) u -= nt0;
   const ca_gemm_problem P = L.p[prob];
   const int m0 = L.thin_row0[prob] + THIN_M * (int)blockIdx.y, n0 = u * THIN_N, M = P.M;
   if (m0 >= M) return;  // (two problems with different thin row counts share a grid: whole workgroup)
@@ -1085,17 +1124,15 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
-  stage(1, 1);
-  stage(2, 2);
+#pragma unroll
+  for (int i = 0; i < THIN_SLOTS - 1; ++i) stage(i, i);
   for (int t = 0; t < nk; ++t) {
-    if constexpr (NP == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // all but my two youngest K tiles
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    ca_wait_vmcnt_imm<NP * (THIN_SLOTS - 2)>();  // all but my SLOTS - 2 youngest K tiles have landed: tile t is there
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    stage((t + 3) & 3, t + 3);
-    const char *sb = smem + (t & 3) * THIN_STAGE;
+    stage((t + THIN_SLOTS - 1) % THIN_SLOTS, t + THIN_SLOTS - 1);
+    const char *sb = smem + (t % THIN_SLOTS) * THIN_STAGE;
     bf16x8 af[MF][2], wf[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1132,20 +1169,28 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) bias[t] = (float)b8[t];
   }
-  if (epi == CA_EPI_QKV_NORM_ROPE && n0 < (P.n_split / 3) * 2) {  // this tile = one head of q or k
+  if (NW == 4 && epi == CA_EPI_QKV_NORM_ROPE && n0 < (P.n_split / 3) * 2) {  // this tile = one head of q or k
     const int hd = P.n_split / 3;
     const bool is_q = n0 < hd;
+    const bool add_q = is_q && P.q_prerope && P.qpre_f32 == 3;
     const bf16 *nscale = (const bf16 *)(is_q ? P.norm_q : P.norm_k);
     float *part = (float *)smem;  // [rows][4 column-waves]
     float x[MF][8];
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) {
       float sq = 0.f;
+      float qa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (add_q) {
+        const float *qp = (const float *)P.q_prerope + (size_t)min(m0 + 16 * mi + l15, M - 1) * P.ldp + n0 + wn * 32 + 8 * g;
+        const f32x4 a0 = *(const f32x4 *)qp, a1 = *(const f32x4 *)(qp + 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { qa[t] = a0[t]; qa[4 + t] = a1[t]; }
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[mi][j][r] + bias[4 * j + r];
+          const float v = (add_q ? acc[mi][j][r] + qa[4 * j + r] : acc[mi][j][r]) + bias[4 * j + r];
           x[mi][4 * j + r] = v;
           sq = __builtin_fmaf(v, v, sq);  // (explicit: the thin-row kernel must round as this one does)
         }
@@ -1256,21 +1301,22 @@ __global__ __launch_bounds__(256) void ca_gemm_thin_kernel(const GemmLaunch L) {
   }
 }
 
-template <int MF>
+template <int MF, int NW>
 int launch_thin_mf(const GemmLaunch &L, int groups, hipStream_t stream) {
-  using TC = ThinCfg<MF>;
+  using TC = ThinCfg<MF, NW>;
   static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
   const unsigned long long dev_bit = ca_device_bit();
   if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
-    hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_thin_kernel<MF>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       TC::LDS);
+    hipError_t e = hipFuncSetAttribute((const void *)ca_gemm_thin_kernel<MF, NW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, TC::LDS);
     if (e != hipSuccess) {
       ca_set_error("ca_gemm_bf16: hipFuncSetAttribute(%d bytes LDS): %s", TC::LDS, hipGetErrorString(e));
       return CA_ERR_LAUNCH;
     }
     attr_done.fetch_or(dev_bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(ca_gemm_thin_kernel<MF>, dim3(L.thin_nt[0] + L.thin_nt[1], groups), dim3(256), TC::LDS, stream, L);
+  hipLaunchKernelGGL((ca_gemm_thin_kernel<MF, NW>), dim3((L.thin_nt[0] + L.thin_nt[1]) * (4 / NW), groups), dim3(64 * NW),
+                     TC::LDS, stream, L);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ca_set_error("ca_gemm_bf16: thin-row launch failed: %s", hipGetErrorString(e));
@@ -1281,10 +1327,21 @@ int launch_thin_mf(const GemmLaunch &L, int groups, hipStream_t stream) {
 
 int launch_thin(const GemmLaunch &L, hipStream_t stream) {
   int rows = 1;  // rows of the longest thin part
+  bool heads = false;   // the fused QK-norm + RoPE epilogue needs a head's 128 columns in one workgroup
   for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i)
-    if (L.thin_nt[i]) rows = max(rows, L.p[i].M - L.thin_row0[i]);
-  if (rows <= 32) return launch_thin_mf<2>(L, 1, stream);
-  return launch_thin_mf<4>(L, (rows + 63) / 64, stream);  // 64 rows per workgroup, one grid row per 64
+    if (L.thin_nt[i]) {
+      rows = max(rows, L.p[i].M - L.thin_row0[i]);
+      heads |= L.p[i].epilogue == CA_EPI_QKV_NORM_ROPE;
+    }
+  // one-wave workgroups (4 x the CUs streaming weight rows) for the rows of a batch's concept tokens; the 64-row form
+  // -- the conditioning vectors of the modulation GEMM, longer thin parts -- keeps 4 waves (the weights stream once per
+  // 64 rows either way, and its N is a million columns: the chip is full)
+  // ... where the launch is short of workgroups (N / 128 <= 256), not for the modulation GEMM's million columns
+  static const int narrow_env = ca_ab_env("CA_GEMM_THIN_NARROW", 1);
+  const bool narrow = narrow_env && !heads && L.thin_nt[0] + L.thin_nt[1] <= 256;
+  if (rows <= 32) return narrow ? launch_thin_mf<2, 1>(L, 1, stream) : launch_thin_mf<2, 4>(L, 1, stream);
+  if (narrow) return launch_thin_mf<4, 1>(L, (rows + 63) / 64, stream);   // (flux-dev's 5 x 8 concept rows)
+  return launch_thin_mf<4, 4>(L, (rows + 63) / 64, stream);
 }
 
 template <int NL, int NHI, bool FP8 = false>
@@ -1530,9 +1587,13 @@ int gemm_impl(const ca_gemm_problem *problems, int32_t n_problems, int32_t tile,
         }
         break;
       case CA_EPI_QKV_NORM_ROPE:
-        if (tile != CA_TILE_PP_256x256 || p.n_split <= 0 || p.n_split % 768 || p.n_split > p.N || !p.norm_q ||
+        // (N == n_split / 3: the q third alone -- the low-plane q projection of a captured layer, qpre_f32 = 3)
+        if (tile != CA_TILE_PP_256x256 || p.n_split <= 0 || p.n_split % 768 ||
+            (p.n_split > p.N && p.N != p.n_split / 3) || !p.norm_q ||
             !p.norm_k || !p.rope || (p.n_split < p.N && (!p.out2 || p.ld2 % 8 || p.ld2 < p.N - p.n_split)) ||
-            p.ldc < p.n_split || (p.q_prerope && (p.ldp % (p.qpre_f32 ? 4 : 8) || p.ldp < p.n_split / 3 || p.qpre_f32 < 0 || p.qpre_f32 > 2)) ||
+            p.ldc < (p.N < p.n_split ? p.N : p.n_split) ||
+            (p.q_prerope && (p.ldp % (p.qpre_f32 ? 4 : 8) || p.ldp < p.n_split / 3 || p.qpre_f32 < 0 || p.qpre_f32 > 3)) ||
+            (p.qpre_f32 == 3 && (!p.q_prerope || fp8)) ||
             (p.qk_f16 != 0 && p.qk_f16 != 1) ||
             (((uintptr_t)p.norm_q | (uintptr_t)p.norm_k | (uintptr_t)p.rope | (uintptr_t)p.q_prerope |
               (uintptr_t)p.out2) & 15)) {

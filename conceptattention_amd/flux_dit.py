@@ -718,35 +718,51 @@ class HipFluxDiT:
         indep = bool(split and self.capture_independent_image and self.split_q_attention)
         qk16 = self._qk16(capture and not self.capture_independent_image)
         self._layer_indep = indep
-        if split:   # q weights applied to the low plane: image rows and the concept rows (text rows are not captured)
-            # (256 x 256 tiles named: the automatic choice prices the concept rows' problem and lands on 256 x 128,
-            # 376 vs 332 us per 5-item launch)
-            ops.gemm([ops.Gemm(self.XML[oI:], W[b + "img_attn.qkv.weight"][:H], None, self.QD[oI:]),
-                      ops.Gemm(self.XML[:oT], W[b + "txt_attn.qkv.weight"][:H], None, self.QD[:oT])],
-                     L.TILE_PP_256x256 if B * Li >= 4096 else L.TILE_AUTO)
-        self._launch_gemm([G(fp8_qkv, XM[oI:], rows(XM8, oI, n), rows(XMS, oI, n), b + "img_attn.qkv.weight",
-                             W.tensors.get(b + "img_attn.qkv.bias"), QKV[oI:],
-                             L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
-                             norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[oI:],
-                             q_prerope=None if qpre is None else qpre[oI:], q_out_scale=self._q_out_scale(),
-                             qpre_raw=split, qk_f16=qk16),
-                           G(fp8_qkv, XM[:oI], rows(XM8, 0, oI), rows(XMS, 0, oI), b + "txt_attn.qkv.weight",
-                             W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:oI],
-                             L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
-                             norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:oI],
-                             q_prerope=None if qpre is None else qpre[:oI], q_out_scale=self._q_out_scale(),
-                             qpre_raw=split, qk_f16=qk16)])
-        if split:
-            # ... and (round 4) the ATTENTION's q of those rows from the same unrounded projection: rotated, scaled and
-            # stored over what the epilogue wrote.  A single output-space map: 7.8e-4 -> 2.5e-4 from the fp32 oracle
-            # (the operand's rounding reaches the map through q; tests/tools/diag_out_space.py).  The image therefore
-            # depends, at rounding level, on which layers' maps are requested; CA_SPLIT_Q_ATTENTION=0 restores q.
-            sq = dict(q_out_scale=self._q_out_scale(), q_f16=qk16) if self.split_q_attention else {}
+        def qkv_launch():
+            self._launch_gemm([G(fp8_qkv, XM[oI:], rows(XM8, oI, n), rows(XMS, oI, n), b + "img_attn.qkv.weight",
+                                 W.tensors.get(b + "img_attn.qkv.bias"), QKV[oI:],
+                                 L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "img_attn.norm.query_norm.scale"],
+                                 norm_k=W[b + "img_attn.norm.key_norm.scale"], rope=self.ROPE[oI:],
+                                 q_prerope=None if qpre is None else qpre[oI:], q_out_scale=self._q_out_scale(),
+                                 qpre_raw=split, qk_f16=qk16),
+                               G(fp8_qkv, XM[:oI], rows(XM8, 0, oI), rows(XMS, 0, oI), b + "txt_attn.qkv.weight",
+                                 W.tensors.get(b + "txt_attn.qkv.bias"), QKV[:oI],
+                                 L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=W[b + "txt_attn.norm.query_norm.scale"],
+                                 norm_k=W[b + "txt_attn.norm.key_norm.scale"], rope=self.ROPE[:oI],
+                                 q_prerope=None if qpre is None else qpre[:oI], q_out_scale=self._q_out_scale(),
+                                 qpre_raw=split, qk_f16=qk16)])
+        # (256 x 256 tiles named for the low-plane launches: the automatic choice prices the concept rows' problem and
+        # lands on 256 x 128, 376 vs 332 us per 5-item launch)
+        lo_tile = L.TILE_PP_256x256 if B * Li >= 4096 else L.TILE_AUTO
+        if split and self.split_q_attention:
+            # (round 5) the q weights applied to the low plane of y -- image rows and concept rows; text rows are not
+            # captured -- with the correction, the RMS norm, the rotation and the store of the ATTENTION's q fused into
+            # that launch's epilogue (qpre_f32 = 3): the main launch leaves the hi plane's raw q projection in QPRE, this
+            # one adds its own product, normalises (QPRE <- the cross-attention-space vectors, fp32) and writes the
+            # rotated, scaled q over what the main epilogue formed from bf16(y).  A single output-space map: 7.8e-4 ->
+            # 2.5e-4 from the fp32 oracle (the operand's rounding reaches the map through q; tests/tools/diag_out_space.py).
+            # Rounds 3-4 had a second GEMM output (QD) and ca_qpre_finish_rope_f32 for it: 18 instead of 10 bytes per
+            # element past the GEMM and 2 launches more per captured layer.
+            qkv_launch()
             q_acc = self.QACC if indep else qs
-            ops.qpre_finish(qpre[oI:], self.QD[oI:], W[b + "img_attn.norm.query_norm.scale"], NH,
-                            **(dict(rope=self.ROPE[oI:], q_out=q_acc[oI:], **sq) if sq else {}))
-            ops.qpre_finish(qpre[:oT], self.QD[:oT], W[b + "txt_attn.norm.query_norm.scale"], NH,
-                            **(dict(rope=self.ROPE[:oT], q_out=q_acc[:oT], **sq) if sq else {}))
+            lo = dict(epilogue=L.EPI_QKV_NORM_ROPE, n_split=3 * H, q_out_scale=self._q_out_scale(), qpre_add=True,
+                      qk_f16=qk16)
+            ops.gemm([ops.Gemm(self.XML[oI:], W[b + "img_attn.qkv.weight"][:H], None, q_acc[oI:],
+                               norm_q=W[b + "img_attn.norm.query_norm.scale"], norm_k=W[b + "img_attn.norm.key_norm.scale"],
+                               rope=self.ROPE[oI:], q_prerope=qpre[oI:], **lo),
+                      ops.Gemm(self.XML[:oT], W[b + "txt_attn.qkv.weight"][:H], None, q_acc[:oT],
+                               norm_q=W[b + "txt_attn.norm.query_norm.scale"], norm_k=W[b + "txt_attn.norm.key_norm.scale"],
+                               rope=self.ROPE[:oT], q_prerope=qpre[:oT], **lo)], L.TILE_PP_256x256)
+        elif split:
+            # split_q_attention = False (A/B aid): only the cross-attention-space vectors take the correction; the
+            # attention's q stays the main epilogue's (rounds 3's route: second GEMM output + finish kernel)
+            ops.gemm([ops.Gemm(self.XML[oI:], W[b + "img_attn.qkv.weight"][:H], None, self.QD[oI:]),
+                      ops.Gemm(self.XML[:oT], W[b + "txt_attn.qkv.weight"][:H], None, self.QD[:oT])], lo_tile)
+            qkv_launch()
+            ops.qpre_finish(qpre[oI:], self.QD[oI:], W[b + "img_attn.norm.query_norm.scale"], NH)
+            ops.qpre_finish(qpre[:oT], self.QD[:oT], W[b + "txt_attn.norm.query_norm.scale"], NH)
+        else:
+            qkv_launch()
         # K8+K9: per item, joint text+image attention and the concept rows; one launch (concept problems first)
         f32img = self._f32_image_vectors(capture, heatmaps)
 

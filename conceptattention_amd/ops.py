@@ -65,6 +65,8 @@ class Gemm:
     q_prerope: Optional[torch.Tensor] = None   # bf16 or fp32 [M, heads*128]
     q_out_scale: float = 0.0                   # QKV_NORM_ROPE: rotated q times this before rounding (0 = 1)
     qpre_raw: bool = False                     # fp32 q_prerope receives the projection BEFORE its norm (qpre_finish)
+    qpre_add: bool = False                     # fp32 q_prerope HOLDS such a raw projection: added before the norm, then
+                                               # overwritten with the normalised vector (qpre_f32 = 3; N = n_split / 3)
     qk_f16: bool = False                       # QKV_NORM_ROPE: rotated q / k stored as fp16 bits (attention(qk_f16=True))
     a_scale: Optional[torch.Tensor] = None  # fp8 mode: a, w are uint8 (e4m3 bytes) with fp32 row scales
     w_scale: Optional[torch.Tensor] = None  # ([M] and [N]); the launch then goes to ca_gemm_fp8
@@ -123,10 +125,10 @@ def gemm(problems: Sequence[Gemm], tile: int = L.TILE_AUTO) -> None:
                     raise ValueError(f"gemm[{i}]: q_prerope must be bf16 or fp32")
                 p.q_prerope, p.ldp = _chk(g.q_prerope, g.q_prerope.dtype, "q_prerope").data_ptr(), g.q_prerope.stride(0)
                 p.qpre_f32 = int(g.q_prerope.dtype == torch.float32)
-                if g.qpre_raw:
-                    if not p.qpre_f32:
-                        raise ValueError(f"gemm[{i}]: qpre_raw needs an fp32 q_prerope")
-                    p.qpre_f32 = 2
+                if g.qpre_raw or g.qpre_add:
+                    if not p.qpre_f32 or (g.qpre_raw and g.qpre_add):
+                        raise ValueError(f"gemm[{i}]: qpre_raw / qpre_add (one of them) need an fp32 q_prerope")
+                    p.qpre_f32 = 2 if g.qpre_raw else 3
             if g.out2 is not None:
                 p.out2, p.ld2 = _chk(g.out2, torch.bfloat16, "out2").data_ptr(), g.out2.stride(0)
         elif g.epilogue == L.EPI_SPLIT_GELU:

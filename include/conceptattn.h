@@ -67,7 +67,8 @@ enum {
                             /* n >= n_split: out2 = gelu_tanh(acc+bias), column n-n_split  */
                             /* (single block linear1 -> qkv | mlp, single_stream_block:49) */
   CA_EPI_QKV_NORM_ROPE = 4  /* qkv projection with QKNorm + RoPE fused (256x256 ping-pong tile only):      */
-                            /* columns [0, n_split) are q|k|v thirds of heads*128 columns each;             */
+                            /* columns [0, n_split) are q|k|v thirds of heads*128 columns each (or, with    */
+                            /* N = n_split / 3, the q third alone);                                          */
                             /* q, k: out = rope(rmsnorm(acc+bias) * norm_{q,k}), optional q_prerope store;   */
                             /* v: out = acc + bias; columns >= n_split: out2 = gelu_tanh(acc+bias)           */
                             /* (flux/modules/layers.py:63-84, flux/math.py:25-30, double_stream_block:189)  */
@@ -111,7 +112,11 @@ typedef struct {
                            /* cross-attention-space vectors of modified_double_stream_block.py:189-190 without     */
                            /* their bf16 rounding (the heat-map logits are then formed from fp32 q on both sides); */
                            /* 2 = fp32 too, but the q projection (acc + bias) BEFORE its RMS norm: the caller adds */
-                           /* a correction and normalises with ca_qpre_finish_f32                                  */
+                           /* a correction and normalises with ca_qpre_finish_f32;                                 */
+                           /* 3 = (round 5) that correction fused: q_prerope holds such a raw projection on ENTRY, */
+                           /* it is added to acc + bias before the norm and overwritten with the normalised vector */
+                           /* -- the low-plane q projection of a captured layer (N = n_split / 3: the q third      */
+                           /* alone, `out` = the attention's q rows): one launch instead of GEMM + finish kernel   */
   float q_out_scale;       /* QKV_NORM_ROPE: the rotated q is multiplied by this in fp32 before its ONE rounding   */
                            /* to bf16 (0 = 1.0; k, v and q_prerope are not scaled).  With softmax_scale * log2(e)  */
                            /* here, ca_attn_fwd_bf16(scale = CA_ATTN_Q_PRESCALED) needs no per-score multiply      */

@@ -476,6 +476,74 @@ def test_split_q_capture_chain_matches_fp32_projection():
         ops.qpre_finish(qraw, d, nq, nh, rope=rope_t[:5].contiguous(), q_out=outq[:, :H])
 
 
+@pytest.mark.parametrize("M", [300, 20, 513])
+@pytest.mark.parametrize("f16", [True, False])
+def test_low_plane_q_projection_with_fused_finish(M, f16):
+    """Round 5: the low-plane q projection with the correction, the RMS norm, the rotation and the store of the
+    attention's q fused into its epilogue (ca_gemm_problem.qpre_f32 = 3, N = n_split / 3) against the two-step route it
+    replaces (second GEMM output + ca_qpre_finish_rope_f32): the same values up to the order in which a head's 128
+    squares are summed (the cross-space vector within 2e-6 relative, the stored q within one ulp of its type on < 2 %
+    of the elements), and against the fp32 reference of the unrounded projection.  M = 300: full tiles + a thin last row
+    tile; M = 20: the thin-row kernel alone (the concept rows); M = 513: a 1-row last tile."""
+    from oracle import flux_oracle as O
+    nh, H = 2, 256
+    g = torch.Generator(device="cpu").manual_seed(M)
+    x = (torch.randn(M, H, generator=g) * 1.5).to(DEV)
+    sh, sc = (torch.randn(H, generator=g) * 0.2).to(DEV), (torch.randn(H, generator=g) * 0.3).to(DEV)
+    w, b = rnd(3 * H, H, scale=0.08), rnd(3 * H)
+    nq, nk = (0.5 + torch.rand(128, generator=g)).bfloat16().to(DEV), (0.5 + torch.rand(128, generator=g)).bfloat16().to(DEV)
+    rope_t = torch.randn(M, 64, 2, generator=g).to(DEV)
+    rope_t = (rope_t / rope_t.norm(dim=-1, keepdim=True)).contiguous()
+    hi = torch.zeros(M, H, device=DEV, dtype=torch.bfloat16)
+    lo = torch.zeros_like(hi)
+    ops.ln_modulate(x, hi, [(M, sh, sc)], out_lo=lo)
+    y32 = (1 + sc) * torch.nn.functional.layer_norm(x, (H,), eps=1e-6) + sh
+
+    def main_launch():
+        qraw = torch.zeros(M, H, device=DEV)
+        out = torch.zeros(M, 3 * H, device=DEV, dtype=torch.bfloat16)
+        ops.gemm([ops.Gemm(hi, w, b, out, L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=nq, norm_k=nk, rope=rope_t,
+                           q_prerope=qraw, qpre_raw=True, q_out_scale=SL2, qk_f16=f16)], L.TILE_PP_256x256)
+        return qraw, out
+    # two-step route
+    qa, outa = main_launch()
+    d = torch.zeros(M, H, device=DEV)
+    ops.gemm([ops.Gemm(lo, w[:H], None, d)], L.TILE_PP_256x256)
+    ops.qpre_finish(qa, d, nq, nh, rope=rope_t, q_out=outa[:, :H], q_out_scale=SL2, q_f16=f16)
+    # fused route
+    qb, outb = main_launch()
+    kv = outb[:, H:].clone()
+    ops.gemm([ops.Gemm(lo, w[:H], None, outb[:, :H], L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=nq, norm_k=nk,
+                       rope=rope_t, q_prerope=qb, qpre_add=True, q_out_scale=SL2, qk_f16=f16)], L.TILE_PP_256x256)
+    torch.cuda.synchronize()
+    assert torch.equal(outb[:, H:], kv)                                   # k and v are not touched
+    assert (qa - qb).abs().max() <= 2e-6 * qa.abs().max()
+    view = (lambda t_: t_.contiguous().view(torch.float16).float()) if f16 else (lambda t_: t_.float())
+    a_, b_ = view(outa[:, :H]), view(outb[:, :H])
+    assert (a_ - b_).abs().max() <= (2.0 ** -10 if f16 else 2.0 ** -7) * a_.abs().max()
+    assert (a_ != b_).float().mean() < 0.02
+    ref = O.rms_norm((y32.cpu() @ w[:H].float().cpu().t() + b[:H].float().cpu()).view(M, nh, 128),
+                     nq.float().cpu()).reshape(M, H)
+    assert (qb.cpu() - ref).abs().max() < 2e-4
+    # a row's bits do not depend on the tile form it runs in: the same rows as the head of a longer problem
+    if M == 20:
+        Mb = 256 + 20
+        hi2 = torch.cat((torch.zeros(256, H, device=DEV, dtype=torch.bfloat16), hi))
+        lo2 = torch.cat((torch.zeros(256, H, device=DEV, dtype=torch.bfloat16), lo))
+        rope2 = torch.cat((torch.zeros(256, 64, 2, device=DEV), rope_t)).contiguous()
+        q2 = torch.zeros(Mb, H, device=DEV)
+        out2 = torch.zeros(Mb, 3 * H, device=DEV, dtype=torch.bfloat16)
+        ops.gemm([ops.Gemm(hi2, w, b, out2, L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=nq, norm_k=nk, rope=rope2,
+                           q_prerope=q2, qpre_raw=True, q_out_scale=SL2, qk_f16=f16)], L.TILE_PP_256x256)
+        ops.gemm([ops.Gemm(lo2, w[:H], None, out2[:, :H], L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=nq, norm_k=nk,
+                           rope=rope2, q_prerope=q2, qpre_add=True, q_out_scale=SL2, qk_f16=f16)], L.TILE_PP_256x256)
+        assert torch.equal(q2[256:], qb) and torch.equal(out2[256:, :H], outb[:, :H])
+    with pytest.raises(ValueError):   # qpre_add needs the fp32 buffer
+        ops.gemm([ops.Gemm(lo, w[:H], None, outb[:, :H], L.EPI_QKV_NORM_ROPE, n_split=3 * H, norm_q=nq, norm_k=nk,
+                           rope=rope_t, q_prerope=torch.zeros(M, H, device=DEV, dtype=torch.bfloat16), qpre_add=True)],
+                 L.TILE_PP_256x256)
+
+
 def test_heatmap_logits_fp32_image_vectors():
     """fp32 image AND concept vectors (the fp32 q_prerope store): the same k order as the bf16-image form."""
     Lp, dim, C = 300, 3072, 6
