@@ -560,6 +560,20 @@ def main():
             roof["note"] = ("path_frac and concept_attention_block.mfma_frac are fractions of the 2.5 PFLOP/s bf16 "
                             "peak (attention and the small kernels stay bf16); frac is the e4m3 GEMM kernel "
                             "against the 5 PFLOP/s fp8 peak")
+        # what exactly runs on e4m3 operands in fp8 mode, per workload (the sweep's line did not say that the
+        # qkv projection of all 19 captured layers stays bf16)
+        if wl == "generate":
+            fp8_scope = (f"qkv / proj / mlp.0 / mlp.2 / linear1 / linear2 of every block EXCEPT double blocks {layer_indices}, "
+                         "which stay bf16 entirely (the layers whose maps are returned; pipeline.fp8_keep_heatmap_layers): "
+                         f"{p.depth - len(layer_indices)} of {p.depth} double blocks and all {p.depth_single_blocks} single blocks in e4m3")
+        else:
+            cap = layer_indices if wl == "encode" else list(range(p.depth))
+            fp8_scope = (f"proj / mlp.0 / mlp.2 of all {p.depth} double blocks and the qkv projection of the "
+                         f"{p.depth - len(cap)} double blocks whose maps are not requested in e4m3; the qkv projection (and the "
+                         f"low-plane q projection) of the {len(cap)} captured layers stays bf16 "
+                         "(HipFluxDiT.fp8_bf16_qkv_when_captured: their q / k / v ARE the vectors of the maps) -- "
+                         f"{75 + 25 * (p.depth - len(cap)) // p.depth} % of the double blocks' projection FLOPs in e4m3; attention, "
+                         "LayerNorm, heat maps bf16 / fp32 as always")
         res = {
             "metric": metric,
             "value": calls * maps_per_item / elapsed,
@@ -574,8 +588,7 @@ def main():
                        "tflop_per_call": flops_call / 1e12, "parallelism": f"replica x{world} (work items round-robin)",
                        "items_per_forward": args.batch, "streams_per_gpu": args.streams,
                        "residual_stream": args.residual,
-                       **({"fp8_scope": "qkv/proj/mlp/linear1/linear2 of all blocks except double blocks "
-                                        f"{layer_indices} (the heat-map layers stay bf16)"} if fp8 else {})},
+                       **({"fp8_scope": fp8_scope} if fp8 else {})},
             "calls_per_s": calls / elapsed,
             "timed_region": {"wall_s": elapsed, "gpu_stream_s": gpu_elapsed, "host_enqueue_s": t_enqueued,
                              "note": "rank 0: wall = max over ranks of barrier-to-barrier time (what value uses); "

@@ -70,11 +70,14 @@ class ConceptAttentionFluxPipeline:
     def __init__(self, model_name: str = "flux-schnell", offload_model: bool = False, device="cuda:0",
                  weights="synthetic", weight_seed: int = 0, text_encoder=None, autoencoder=None,
                  params=None, n_text_tokens: Optional[int] = None, precision: str = "bf16",
-                 residual_dtype=torch.float32):
+                 residual_dtype=torch.float32, capture_independent_image: bool = False):
         """model_name / offload_model / device as in the reference (:100-113).  ``weights`` is
         "synthetic" (seeded random init), a path to a flux1-*.safetensors file, or a state dict.
         ``precision="fp8"`` runs the large projections on e4m3 operands (HipFluxDiT.set_precision);
-        ``residual_dtype`` is the storage type of the residual streams (fp32 by default, HipFluxDiT.__init__)."""
+        ``residual_dtype`` is the storage type of the residual streams (fp32 by default, HipFluxDiT.__init__);
+        ``capture_independent_image=True`` makes the returned latent (and every map) independent of ``layer_indices``
+        bit for bit, as in the reference, for the image rows' attention twice in the captured layers
+        (HipFluxDiT.capture_independent_image; INTEGRATION.md)."""
         if params is None and model_name not in configs:
             raise KeyError(model_name)
         self.model_name = model_name
@@ -90,6 +93,7 @@ class ConceptAttentionFluxPipeline:
                                             n_text_tokens=n_text_tokens, residual_dtype=residual_dtype)
         self.model = self.flux_generator.model
         self.model.set_precision(precision)
+        self.model.capture_independent_image = bool(capture_independent_image)
         self.fp8_keep_heatmap_layers = True  # generate path only; the sweeps/encode path run every block in fp8
         self._replicas = [self.model]  # activation sets that share self.model's weights (one per stream)
         self._streams = []
@@ -157,6 +161,8 @@ class ConceptAttentionFluxPipeline:
                                              precision=self.model.precision,
                                              residual_dtype=self.model.residual_dtype)
                                   .set_precision(self.model.precision, self.model.keep_bf16_layers))
+        for r in self._replicas:
+            r.capture_independent_image = self.model.capture_independent_image
         while len(self._streams) < n_streams:
             self._streams.append(torch.cuda.Stream(device=self.device))
         cur = torch.cuda.current_stream(self.device)
@@ -413,6 +419,8 @@ class ConceptAttentionFluxPipeline:
                                              precision=self.model.precision,
                                              residual_dtype=self.model.residual_dtype)
                                   .set_precision(self.model.precision, self.model.keep_bf16_layers))
+        for r in self._replicas:
+            r.capture_independent_image = self.model.capture_independent_image
         while len(self._streams) < n_streams:
             self._streams.append(torch.cuda.Stream(device=self.device))
         cur = torch.cuda.current_stream(self.device)
