@@ -1,7 +1,14 @@
 set -e
-O=gpurun_out/r05l; mkdir -p $O
-python tools/thin_ab.py > $O/thin_micro_head.txt 2>&1; cat $O/thin_micro_head.txt
-CA_LIB_PATH=tools/ab/thin_slots4/libca.so python tools/thin_ab.py > $O/thin_micro_slots4.txt 2>&1; cat $O/thin_micro_slots4.txt
-python tools/bench_ab.py --reps 3 tools/ab/thin_slots4/libca.so HEAD > $O/thin_ring_ab.txt 2>&1; cat $O/thin_ring_ab.txt
-python -m pytest tests/test_kernels_gpu.py tests/test_round2_gpu.py -x -q -k "gemm or modulation or batched" > $O/tests_k.log 2>&1 || (tail -40 $O/tests_k.log; exit 1)
-tail -2 $O/tests_k.log
+O=gpurun_out/r05m; mkdir -p $O
+for i in 1 2; do
+for mode in "--no-kernel-timing" ""; do
+python3 bench.py --workload sweep --steps 10 --warmup 1 --no-cpu-baseline --no-solo-check --no-block-timing $mode > $O/s.json 2>>$O/err.txt
+python3 -c "
+import json; d=json.load(open('$O/s.json')); print('sweep steps 10 [$mode]', round(d['ms_per_step'],2), {k: round(v,4) for k,v in d['timed_region'].items() if k!='note'})"
+done
+done
+for mode in "--no-kernel-timing" ""; do
+python3 bench.py --workload encode --steps 10 --warmup 1 --no-cpu-baseline --no-solo-check --no-block-timing $mode > $O/s.json 2>>$O/err.txt
+python3 -c "
+import json; d=json.load(open('$O/s.json')); print('encode steps 10 [$mode]', round(d['ms_per_step'],2), {k: round(v,4) for k,v in d['timed_region'].items() if k!='note'})"
+done
