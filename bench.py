@@ -283,7 +283,8 @@ def main():
         # (encode / sweep: a group is one ~0.1 s forward; the chip needs a few of them after the idle seconds of weight
         # and input set-up before its clocks are where a sustained run holds them -- a timed region that starts on the
         # second forward after idle measured 110-150 ms per forward for the same 106 ms of kernels, round 5)
-        for _ in range(1 if wl == "generate" else 5):
+        # (--profile-mode keeps exactly one warm-up group: tools/profile_round.py checks Calls == 2 x the counted launches)
+        for _ in range(1 if (wl == "generate" or args.profile_mode) else 5):
             run_many(warm_items, args.streams, args.batch)
         # a ragged group (steps not a multiple of --batch) is a forward of another shape: build its activation set
         # and kernels before the timed region as well (HipFluxDiT keeps the few most recent activation sets)
