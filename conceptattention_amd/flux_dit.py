@@ -250,6 +250,7 @@ class HipFluxDiT:
         # generate call with 4 of 57 layers captured; +15 % of a 19-layer sweep forward); single output-space maps then
         # carry k's bf16 rounding again (measured in the same test file).
         self.capture_independent_image = False
+        self._layer_indep = False   # (set per layer by _double_block, read by _capture)
         # fp8 mode: the qkv projection of a layer whose maps are requested stays bf16 (_double_block)
         self.fp8_bf16_qkv_when_captured = os.environ.get("CA_FP8_QKV_BF16_CAPTURED", "1") != "0"
         # the heat-map updates of a captured layer (all work items, both spaces) as ONE ca_heatmap_fused launch; False =

@@ -37,12 +37,14 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(L.GemmProblem) == 14 * 8 + 20 * 4   # 16 int32 + qpre_f32 + float q_out_scale + qk_f16 + pad
     assert ctypes.sizeof(L.AttnProblem) == 9 * 8 + 8 * 4 + 3 * 4 + 4  # trailing pad to 8-byte alignment
     assert ctypes.sizeof(L.ModSegment) == 24 and ctypes.sizeof(L.NormSegment) == 24
+    assert ctypes.sizeof(L.HeatmapProblem) == 5 * 8 + 4 * 4 + 2 * 4   # ca_heatmap_problem: 64 bytes
 
 
 def _header_struct_fields(name):
     """(type, field) pairs of a `typedef struct { ... } name;` in include/conceptattn.h, in declaration order."""
     text = open(os.path.join(ROOT, "include", "conceptattn.h")).read()
-    body = re.search(r"typedef struct \{(.*?)\}\s*" + name + r"\s*;", text, re.S).group(1)
+    end = re.search(r"\}\s*" + name + r"\s*;", text).start()
+    body = text[text.rfind("typedef struct {", 0, end) + len("typedef struct {"):end]   # (the LAST opener before the name)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     out = []
     for decl in body.split(";"):
@@ -65,6 +67,19 @@ def test_binding_fields_match_header_field_for_field():
     hdr = _header_struct_fields("ca_gemm_problem")
     assert [f for _, f in hdr] == [f for f, _ in L.GemmProblem._fields_]
     assert [_CT[t] for t, _ in hdr] == [t for _, t in L.GemmProblem._fields_]
+
+
+def test_heatmap_problem_fields_match_header_and_arguments_are_checked_without_a_gpu(lib):
+    """ca_heatmap_problem (round 5): header fields == ctypes fields; ca_heatmap_fused rejects bad arguments before any
+    launch (no GPU needed for that)."""
+    hdr = _header_struct_fields("ca_heatmap_problem")
+    assert [f for _, f in hdr] == [f for f, _ in L.HeatmapProblem._fields_]
+    assert [_CT[t] for t, _ in hdr] == [t for _, t in L.HeatmapProblem._fields_]
+    arr = (L.HeatmapProblem * 1)()
+    for bad in (dict(n=0), dict(C=9), dict(dim=12), dict(norm=7), dict()):   # the last: null pointers in the problem
+        rc = lib.ca_heatmap_fused(arr, bad.get("n", 1), 64, bad.get("C", 4), bad.get("dim", 256), bad.get("norm", 0), None)
+        assert rc == -1, bad
+        assert b"ca_heatmap_fused" in lib.ca_last_error()
 
 
 def test_integration_md_stub_is_the_current_abi():
