@@ -901,8 +901,18 @@ class HipFluxDiT:
                 if table is not None:
                     ops.heatmap_softmax_accumulate(self.LOGITS[:C], table[li], hm.per_layer_weight, hm.norm)
         for norm, probs in launches.items():
-            for p0 in range(0, len(probs), L.HEATMAP_MAX_PROBLEMS):
-                ops.heatmap_fused(probs[p0:p0 + L.HEATMAP_MAX_PROBLEMS], norm)
+            # one launch per norm; problems that name an accumulator already in the launch (two requests sharing a
+            # tensor) start a new one: within a launch the updates are unordered read-modify-writes
+            batch, seen = [], set()
+            for pr in probs + [None]:
+                ptrs = set() if pr is None else {t.data_ptr() for t in (pr.acc, pr.acc2) if t is not None}
+                if pr is None or len(batch) == L.HEATMAP_MAX_PROBLEMS or (ptrs & seen):
+                    if batch:
+                        ops.heatmap_fused(batch, norm)
+                    batch, seen = [], set()
+                if pr is not None:
+                    batch.append(pr)
+                    seen |= ptrs
         if return_vectors:
             H = self.hidden_size
             cf = torch.contiguous_format

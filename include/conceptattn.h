@@ -303,7 +303,8 @@ int ca_heatmap_norm_accumulate(const float *logits, int32_t C, int32_t L, int32_
  * experiments/per_layer_segmentation/test_segmentations_per_layer.py:104-114); the logits never reach memory unless
  * `logits` != NULL.  Per patch and concept the arithmetic is that of ca_heatmap_logits_bf16 followed by
  * ca_heatmap_norm_accumulate (same k order, same expressions): the results are bit-identical to the three-launch form.
- * All problems of a call share L, C, dim and norm.  Needs C <= 8 and C * dim * 4 bytes of LDS (<= 96 KB);
+ * All problems of a call share L, C, dim and norm, and no two of them may name the same accumulator (the updates are
+ * plain read-modify-writes by different workgroups).  Needs C <= 8 and C * dim * 4 bytes of LDS (<= 96 KB);
  * CA_ERR_ARG otherwise (the caller then uses the three-launch form). */
 #define CA_HEATMAP_MAX_PROBLEMS 16
 typedef struct {

@@ -67,3 +67,81 @@ def test_heatmap_fused_rejects_bad_arguments():
         ops.heatmap_fused([ops.Heatmap(img, con4, acc[:4].t().contiguous().t(), 1.0)])   # not contiguous [C,L]
     with pytest.raises(ValueError):
         ops.heatmap_fused([ops.Heatmap(img, con4, torch.zeros(4, 64, device=DEV), 1.0)] * 17)
+
+
+def _tiny_forward_kwargs(B):
+    from conceptattention_amd.flux_dit import HipFluxDiT
+    from conceptattention_amd.params import tiny_params
+    from conceptattention_amd.weights import synthetic_inputs, synthetic_state_dict
+    from conceptattention_amd import sampling
+    p = tiny_params()
+    m = HipFluxDiT(p, DEV)
+    m.load_state_dict({k: v.bfloat16().float() for k, v in synthetic_state_dict(p, seed=1).items()})
+    items = [synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=3, seed=2 + j, dtype=torch.bfloat16) for j in range(B)]
+    cat = lambda k: torch.cat([it[k] for it in items], 0).to(DEV)   # noqa: E731
+    kw = dict(img=sampling.patchify(cat("latent")), img_ids=cat("img_ids"), txt=cat("txt"), txt_ids=cat("txt_ids"),
+              concepts=cat("concepts"), concept_ids=cat("concept_ids"), concept_vec=cat("concept_vec"), y=cat("vec"),
+              timesteps=torch.full((B,), 0.6, device=DEV), guidance=torch.zeros(B, device=DEV),
+              stop_after_multimodal_attentions=True, return_vectors=False)
+    return m, p, kw
+
+
+def test_model_fused_heatmaps_equal_the_three_launch_form_and_shared_accumulators_stay_ordered():
+    """The model's capture path (HipFluxDiT._capture) with fused_heatmaps on / off: bit-identical accumulators and
+    per-layer tables for a 3-item forward; and two requests that SHARE their accumulators (a caller summing over items)
+    are split into separate launches -- within one launch the updates of two problems to one tensor would race."""
+    from conceptattention_amd.flux_dit import HeatmapRequest
+    B, C, Lp = 3, 3, 256
+    m, p, kw = _tiny_forward_kwargs(B)
+    res = {}
+    for fused in (True, False):
+        m.fused_heatmaps = fused
+        acc = torch.zeros(B, 2, C, Lp, device=DEV)
+        tab = torch.zeros(B, 2, p.depth, C, Lp, device=DEV)
+        reqs = [HeatmapRequest(tuple(range(p.depth)), 0.5, acc[j, 0], acc[j, 1], per_layer_out=tab[j, 0],
+                               per_layer_cross=tab[j, 1], per_layer_weight=0.25) for j in range(B)]
+        m(heatmaps=reqs, **kw)
+        torch.cuda.synchronize()
+        res[fused] = (acc, tab)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert float(res[True][0].abs().sum()) > 0
+    # shared accumulators: every item adds into the SAME two tensors; fused == three-launch, run after run
+    sums = []
+    for fused in (True, True, False):
+        m.fused_heatmaps = fused
+        a, b = torch.zeros(C, Lp, device=DEV), torch.zeros(C, Lp, device=DEV)
+        m(heatmaps=[HeatmapRequest((1,), 1.0, a, b) for _ in range(B)], **kw)
+        torch.cuda.synchronize()
+        sums.append((a, b))
+    assert all(torch.equal(sums[0][i], s[i]) for s in sums[1:] for i in (0, 1))
+    assert (sums[0][0].sum(0) - B).abs().max().item() < 1e-4      # each item contributes one softmax over the concepts
+    m.fused_heatmaps = True
+
+
+def test_more_than_eight_concepts_take_the_three_launch_form():
+    """ca_heatmap_fused holds all C concept vectors of a problem in LDS (C <= 8); a forward with more concepts must fall
+    back to the logits + weighting launches by itself and still produce normalised maps equal to the stacked route's."""
+    from conceptattention_amd.flux_dit import HeatmapRequest, HipFluxDiT
+    from conceptattention_amd.heatmaps import compute_heatmaps_from_vectors
+    from conceptattention_amd.params import tiny_params
+    from conceptattention_amd.weights import synthetic_inputs, synthetic_state_dict
+    from conceptattention_amd import sampling
+    p = tiny_params()
+    C, Lp = 10, 256
+    assert not ops.heatmap_fused_fits(C, p.hidden_size)
+    m = HipFluxDiT(p, DEV)
+    m.load_state_dict({k: v.bfloat16().float() for k, v in synthetic_state_dict(p, seed=1).items()})
+    it = synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=C, seed=4, dtype=torch.bfloat16)
+    d = {k: v.to(DEV) for k, v in it.items()}
+    kw = dict(img=sampling.patchify(d["latent"]), img_ids=d["img_ids"], txt=d["txt"], txt_ids=d["txt_ids"],
+              concepts=d["concepts"], concept_ids=d["concept_ids"], concept_vec=d["concept_vec"], y=d["vec"],
+              timesteps=torch.full((1,), 0.6, device=DEV), guidance=torch.zeros(1, device=DEV),
+              stop_after_multimodal_attentions=True)
+    req = HeatmapRequest((0, 1), 0.5, torch.zeros(C, Lp, device=DEV), torch.zeros(C, Lp, device=DEV))
+    m(heatmaps=req, return_vectors=False, **kw)
+    _, dd = m(return_vectors=True, **kw)
+    ho = compute_heatmaps_from_vectors(dd["output_space_image_vectors"][None], dd["output_space_concept_vectors"][None],
+                                       [0, 1], [0])
+    assert (req.out_space.sum(0) - 1).abs().max().item() < 1e-5
+    # (the stacked dict carries bf16 vectors, the fused route fp32 concept rows: 2e-3, as tests/test_pipeline_gpu.py)
+    assert (req.out_space.view(1, C, 16, 16).cpu() - ho.float().cpu()).abs().max().item() < 2e-3

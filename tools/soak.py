@@ -66,7 +66,49 @@ def thin_rows():  # 5 full row tiles in the ping-pong walk + 20 rows in the thin
     return x
 
 
-cases = {"thin rows (mlp.2 shape)": thin_rows, "attention": attn, "attention (pre-scaled q: ca_attn4_kernel)": attn4, "mlp0 (grouped, persistent)": mlp0, "linear2 (K=15360)": linear2, "fp8 gemm": fp8}
+# (round 5) the one-wave thin tiles with their 8-slot ring at K = 3072 with a GELU epilogue, the low-plane q projection with
+# the finish fused into its epilogue (full tiles + a thin last tile + the 4-wave thin form for the head epilogue), and the
+# fused heat-map launch (no hand-off of its own; here for the record)
+ag, wg, bg = rnd(1300, 3072), rnd(12288, 3072, scale=0.02), rnd(12288)
+
+
+def thin_rows_gelu():
+    o = torch.empty(1300, 12288, device=dev, dtype=torch.bfloat16)
+    ops.gemm([ops.Gemm(ag, wg, bg, o, L.EPI_GELU_TANH)], L.TILE_PP_256x256)
+    return o
+
+
+Mq = 4096 + 20
+lo_plane, wq = rnd(Mq, 3072, scale=0.01), rnd(3072, 3072, scale=0.02)
+nq = (0.5 + torch.rand(128, device=dev)).bfloat16()
+rope = torch.randn(Mq, 64, 2, device=dev)
+rope = (rope / rope.norm(dim=-1, keepdim=True)).contiguous()
+qraw0 = torch.randn(Mq, 3072, device=dev)
+
+
+def lo_q_fused():
+    qpre = qraw0.clone()
+    qout = torch.zeros(Mq, 3072, device=dev, dtype=torch.bfloat16)
+    kw = dict(epilogue=L.EPI_QKV_NORM_ROPE, n_split=9216, norm_q=nq, norm_k=nq, q_out_scale=0.1275, qpre_add=True, qk_f16=True)
+    ops.gemm([ops.Gemm(lo_plane[:4096], wq, None, qout[:4096], rope=rope[:4096], q_prerope=qpre[:4096], **kw),
+              ops.Gemm(lo_plane[4096:], wq, None, qout[4096:], rope=rope[4096:], q_prerope=qpre[4096:], **kw)],
+             L.TILE_PP_256x256)
+    return torch.cat((qpre.view(torch.int32).flatten(), qout.view(torch.int16).flatten().int()))   # (bit patterns)
+
+
+img_v, con_v = torch.randn(5, 4096, 3072, device=dev), torch.randn(5, 4, 3072, device=dev) * 0.05
+img_b = img_v.bfloat16()
+
+
+def heat_fused():
+    acc = torch.zeros(10, 2, 4, 4096, device=dev)   # (a launch's problems must not share an accumulator)
+    ops.heatmap_fused([ops.Heatmap(img_v[j], con_v[j], acc[j, 0], 0.25, acc[j, 1], 1.0) for j in range(5)] +
+                      [ops.Heatmap(img_b[j], con_v[j], acc[5 + j, 0], 0.25) for j in range(5)])
+    return acc
+
+
+cases = {"thin rows, one-wave tiles (mlp.0 shape, GELU)": thin_rows_gelu, "low-plane q projection, fused finish": lo_q_fused,
+         "fused heat maps (10 problems)": heat_fused, "thin rows (mlp.2 shape)": thin_rows, "attention": attn, "attention (pre-scaled q: ca_attn4_kernel)": attn4, "mlp0 (grouped, persistent)": mlp0, "linear2 (K=15360)": linear2, "fp8 gemm": fp8}
 first = {name: fn() for name, fn in cases.items()}
 torch.cuda.synchronize()
 bad = {name: 0 for name in cases}
