@@ -16,6 +16,7 @@ Fixtures
   single_full.npz                   ONE full-size single block
   block_full_dev.npz                ONE full-size double block at the flux-dev token counts (T=512, C=8)
   block_full_peaky.npz              the block_full case with peaky joint-attention logits (std ~8 nats; a cold text tile)
+  tiny_peaky.npz                    the tiny FULL model (2 double + 2 single blocks) with every key-norm scale x 8
   heatmap_kat.npz                   compute_heatmaps_from_vectors known answers (softmax branch)
   sampler.npz                       get_schedule / prepare-patchify / unpack / denoise (tiny, 2 steps)
   metrics.npz                       segmentation scores of concept_attention/utils.py on seeded masks / maps
@@ -116,6 +117,41 @@ def tiny_model(ref, out_dir, guidance_embed, name):
         arrays["stop_" + k] = v.numpy()
     np.savez_compressed(os.path.join(out_dir, name), **arrays)
     print(name, {k: v.shape for k, v in arrays.items()})
+
+
+def tiny_peaky_state_dict(sd):
+    """Every key_norm.scale of the model x 8 (double blocks: both streams; single blocks), rounded to bf16: the joint-
+    attention logits of all 4 blocks at std ~8 nats.  Shared with the tests through this module."""
+    return {k: ((v * 8.0).bfloat16().float() if k.endswith("key_norm.scale") else v.bfloat16().float())
+            for k, v in sd.items()}
+
+
+def tiny_peaky(ref, out_dir):
+    """Model-level counterpart of block_full_peaky: the whole ModifiedFluxDiT forward (double AND single blocks, final
+    layer) at peaky logits, fp32, on bf16-representable weights and inputs."""
+    from conceptattention_amd.params import tiny_params
+    from conceptattention_amd.weights import synthetic_state_dict, synthetic_inputs
+    from oracle.flux_oracle import patchify
+    p = tiny_params()
+    sd = tiny_peaky_state_dict(synthetic_state_dict(p, seed=1))
+    model = ref["ModifiedFluxDiT"](_ref_params(ref, p)).eval()
+    model.load_state_dict(sd, strict=True)
+    inp = {k: (v.bfloat16().float() if v.is_floating_point() else v)
+           for k, v in synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=3, seed=2).items()}
+    img = patchify(inp["latent"])
+    t = torch.tensor([0.75])
+    with torch.no_grad():
+        pred, d = model(img=img, img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"],
+                        concepts=inp["concepts"], concept_ids=inp["concept_ids"],
+                        concept_vec=inp["concept_vec"], y=inp["vec"], timesteps=t, guidance=torch.tensor([0.0]))
+    # (the reference's compute_heatmaps_from_vectors is hard-wired to 64 x 64 patches: the tests form the maps of these
+    # vectors with the oracle's reduction, which heatmap_kat.npz pins)
+    arrays = {"pred": pred.numpy(), "timestep": t.numpy(),
+              "key_scale_checksum": _checksum(sd["single_blocks.1.norm.key_norm.scale"])}
+    for k, v in d.items():
+        arrays[k] = v.numpy()
+    np.savez_compressed(os.path.join(out_dir, "tiny_peaky.npz"), **arrays)
+    print("tiny_peaky: pred max", pred.abs().max().item())
 
 
 def tiny_ablation(ref, out_dir):
@@ -450,7 +486,7 @@ def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     ref = _import_reference()
-    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "metrics", "full", "fulldev", "temb", "peaky"]
+    which = sys.argv[1:] or ["tiny", "ablation", "heatmap", "sampler", "metrics", "full", "fulldev", "temb", "peaky", "tinypeaky"]
     if "tiny" in which:
         tiny_model(ref, out_dir, False, "tiny_schnell.npz")
         tiny_model(ref, out_dir, True, "tiny_dev.npz")
@@ -470,6 +506,8 @@ def main():
         full_block_dev(ref, out_dir)
     if "peaky" in which:
         full_block_peaky(ref, out_dir)
+    if "tinypeaky" in which:
+        tiny_peaky(ref, out_dir)
 
 
 if __name__ == "__main__":

@@ -87,6 +87,46 @@ def test_tiny_model_matches_oracle(guidance_embed):
     assert maxabs(hm, hm_o) < 3e-3
 
 
+def test_tiny_model_peaky_logits_vs_reference_golden(golden):
+    """Model level at peaky logits (round 5): the whole tiny model -- double blocks, single blocks (linear1's fused
+    QK-norm + RoPE epilogue, the [text | image] attention), final layer -- with every key-norm scale x 8, against the
+    REFERENCE's fp32 forward (tests/golden/tiny_peaky.npz).  Same relative gates as the std-1 tiny test; the heat maps
+    of the HIP vectors against the maps of the reference's vectors (both through reductions pinned elsewhere)."""
+    from oracle.make_goldens import tiny_peaky_state_dict
+    g = golden("tiny_peaky.npz")
+    p = tiny_params()
+    sd = tiny_peaky_state_dict(synthetic_state_dict(p, seed=1))
+    inp = {k: (bf(v) if v.is_floating_point() else v)
+           for k, v in synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=3, seed=2).items()}
+    for qk16 in ("captured", "0"):
+        m = HipFluxDiT(p, DEV)
+        m.qk_f16 = qk16
+        m.load_state_dict(sd)
+        d_in = {k: v.to(DEV) for k, v in inp.items()}
+        pred, d = m(img=O.patchify(inp["latent"]).to(DEV), img_ids=d_in["img_ids"], txt=d_in["txt"], txt_ids=d_in["txt_ids"],
+                    concepts=d_in["concepts"], concept_ids=d_in["concept_ids"], concept_vec=d_in["concept_vec"],
+                    y=d_in["vec"], timesteps=torch.tensor([float(g["timestep"][0])], device=DEV),
+                    guidance=torch.zeros(1, device=DEV))
+        ref_pred = torch.from_numpy(g["pred"])
+        e_pred = maxabs(pred, ref_pred)
+        errs = {}
+        for k in DICT_KEYS:
+            ref = torch.from_numpy(g[k])
+            assert tuple(d[k].shape) == tuple(ref.shape), k
+            errs[k] = maxabs(d[k], ref) / max(ref.abs().max().item(), 1.0)
+        st = {k: v[None] for k, v in d.items()}
+        st_o = {k: torch.from_numpy(g[k])[None] for k in DICT_KEYS}
+        hm = compute_heatmaps_from_vectors(st["output_space_image_vectors"], st["output_space_concept_vectors"],
+                                           layer_indices=[0, 1], timesteps=[0])
+        hm_o = O.compute_heatmaps(st_o["output_space_image_vectors"], st_o["output_space_concept_vectors"], [0, 1], [0])
+        e_hm = maxabs(hm, hm_o)
+        print(f"\n[measured] tiny model, key scales x 8, qk_f16={qk16}: pred {e_pred:.3e} (max |pred| "
+              f"{ref_pred.abs().max().item():.2f}), vectors (rel.) {errs}, output-space maps {e_hm:.3e}")
+        assert e_pred < 3e-2 * max(ref_pred.abs().max().item(), 1.0)
+        assert all(v < 2e-2 for v in errs.values()), errs
+        assert e_hm < 1.5e-2     # (std-1 tiny test: 3e-3; a peaky row passes v's and P's 2^-9 on unaveraged)
+
+
 def test_tiny_stop_after_multimodal_and_fused_heatmaps():
     p, sd, inp = tiny_case()
     _, d_o = O.dit_forward(sd, p, O.patchify(inp["latent"]), inp["img_ids"], inp["txt"], inp["txt_ids"],

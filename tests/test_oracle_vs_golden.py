@@ -147,6 +147,22 @@ def test_full_size_blocks(golden):
     assert _maxabs(y[0, _t(gs["sample_rows"])], gs["out_rows"]) < 2e-4
 
 
+def test_tiny_model_peaky_logits(golden):
+    """The whole tiny model (2 double + 2 single blocks, final layer) with every key-norm scale x 8, made by the
+    reference's ModifiedFluxDiT (oracle/make_goldens.py tinypeaky): the oracle at peaky logits through every block type."""
+    from oracle.make_goldens import tiny_peaky_state_dict
+    g = golden("tiny_peaky.npz")
+    p = tiny_params()
+    sd = tiny_peaky_state_dict(synthetic_state_dict(p, seed=1))
+    inp = {k: (v.bfloat16().float() if v.is_floating_point() else v)
+           for k, v in synthetic_inputs(p, 256, 256, n_txt=8, n_concepts=3, seed=2).items()}
+    pred, d = O.dit_forward(sd, p, O.patchify(inp["latent"]), inp["img_ids"], inp["txt"], inp["txt_ids"], inp["concepts"],
+                            inp["concept_ids"], inp["concept_vec"], _t(g["timestep"]), inp["vec"], torch.tensor([0.0]))
+    assert _maxabs(pred, g["pred"]) < 5e-5
+    for k in O.DICT_KEYS:
+        assert d[k].shape == g[k].shape and _maxabs(d[k], g[k]) < 5e-5, k
+
+
 @pytest.mark.parametrize("case_name", ["iid8", "coldtext"])
 def test_full_size_block_peaky_logits(golden, case_name):
     """block_full's case with peaky joint-attention logits (oracle/full_block_case.PEAKY_CASES: std ~7 nats; a text tile

@@ -145,3 +145,36 @@ def test_more_than_eight_concepts_take_the_three_launch_form():
     assert (req.out_space.sum(0) - 1).abs().max().item() < 1e-5
     # (the stacked dict carries bf16 vectors, the fused route fp32 concept rows: 2e-3, as tests/test_pipeline_gpu.py)
     assert (req.out_space.view(1, C, 16, 16).cpu() - ho.float().cpu()).abs().max().item() < 2e-3
+
+
+def test_heatmap_fused_shape_fuzz():
+    """40 random launches (C 1..8, L 1..700, dim a multiple of 8 up to 1 280 -- below and above one 512-element pass of a
+    lane --, 1..6 problems of mixed vector types, every norm, one or two accumulators) against the three-launch form,
+    bit for bit."""
+    import random
+    rng = random.Random(5)
+    for case in range(40):
+        C, Lp, dim = rng.randint(1, 8), rng.randint(1, 700), 8 * rng.randint(1, 160)
+        norm = rng.choice([L.NORM_SOFTMAX, L.NORM_SPARSEMAX, L.NORM_ENTMAX15])
+        probs, refs = [], []
+        for i in range(rng.randint(1, 6)):
+            img_dt, con_dt = rng.choice([(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                                         (torch.bfloat16, torch.bfloat16)])
+            img = _rand((Lp, dim), 1000 * case + i, 0.3).to(img_dt)
+            con = _rand((C, dim), 2000 * case + i, 0.3).to(con_dt)
+            two = rng.random() < 0.5
+            acc, acc2 = _rand((C, Lp), 3000 * case + i), (_rand((C, Lp), 4000 * case + i) if two else None)
+            w, w2 = rng.random(), rng.random()
+            r_acc, r_acc2 = acc.clone(), (acc2.clone() if two else None)
+            lg = torch.empty(C, Lp, device=DEV)
+            ops.heatmap_logits(img, con, lg)
+            ops.heatmap_softmax_accumulate(lg, r_acc, w, norm)
+            if two:
+                ops.heatmap_softmax_accumulate(lg, r_acc2, w2, norm)
+            probs.append(ops.Heatmap(img, con, acc, w, acc2, w2))
+            refs.append((r_acc, r_acc2))
+        ops.heatmap_fused(probs, norm)
+        torch.cuda.synchronize()
+        for h, (r_acc, r_acc2) in zip(probs, refs):
+            assert torch.equal(h.acc, r_acc), (case, C, Lp, dim, norm)
+            assert r_acc2 is None or torch.equal(h.acc2, r_acc2), (case, C, Lp, dim, norm)
