@@ -121,9 +121,22 @@ def tiny_model(ref, out_dir, guidance_embed, name):
 
 def tiny_peaky_state_dict(sd):
     """Every key_norm.scale of the model x 8 (double blocks: both streams; single blocks), rounded to bf16: the joint-
-    attention logits of all 4 blocks at std ~8 nats.  Shared with the tests through this module."""
-    return {k: ((v * 8.0).bfloat16().float() if k.endswith("key_norm.scale") else v.bfloat16().float())
-            for k, v in sd.items()}
+    attention logits of all 4 blocks at std ~8 nats; the v third of every qkv / linear1 projection x 0.25 (as in
+    full_block_case.PEAKY_CASES["iid8"]: peaky rows return single value vectors, and without it the output-space logits
+    -- std 6.8, up to 44 -- saturate the softmax over the concepts).  Shared with the tests through this module."""
+    out = {}
+    for k, v in sd.items():
+        v = v.bfloat16().float()
+        if k.endswith("key_norm.scale"):
+            v = (v * 8.0).bfloat16().float()
+        elif k.endswith(("_attn.qkv.weight", "_attn.qkv.bias", "linear1.weight", "linear1.bias")):
+            H = v.shape[1] if v.dim() == 2 else (v.shape[0] // 3 if "qkv" in k else None)
+            if H is None:   # linear1.bias: [3H + mlp]; H from the matching weight
+                H = sd[k.replace(".bias", ".weight")].shape[1]
+            v = v.clone()
+            v[2 * H:3 * H] *= 0.25
+        out[k] = v
+    return out
 
 
 def tiny_peaky(ref, out_dir):
