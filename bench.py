@@ -117,7 +117,8 @@ def stub_main(args):
     evidence = D.collective_evidence("cpu")   # the same record the real line carries as "collective"
     if args.stub_evidence:   # TEST ONLY: pretend the record came from an RCCL group with this many ranks / devices
         seen, distinct = (int(v) for v in args.stub_evidence.split(","))
-        evidence = dict(evidence or {}, backend="rccl (torch.distributed 'nccl')", ranks_seen=seen, distinct_devices=distinct)
+        evidence = dict(evidence or {}, backend="rccl (torch.distributed 'nccl')", ranks_seen=seen, distinct_devices=distinct,
+                        pci_bus_ids=[3 + (r if r < distinct else 0) for r in range(world)])   # (known bus ids: conclusive)
     D.check_collective_evidence(evidence, world)
     if rank == 0:
         print(json.dumps({"metric": "STUB (launcher test, no GPU work)", "value": n_timed * C / max(elapsed, 1e-9),

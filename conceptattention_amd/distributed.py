@@ -118,7 +118,11 @@ def check_collective_evidence(ev: dict | None, world: int, rehearsal: bool = Fal
     CA_BENCH_DEVICE rehearsals (several ranks on one GPU on purpose) are exempt (``rehearsal``)."""
     if ev is None or world <= 1 or rehearsal or not str(ev.get("backend", "")).startswith("rccl"):
         return
-    if ev.get("ranks_seen") != world or ev.get("distinct_devices") != world:
+    # (the device count is conclusive only where the PCI bus ids are known: a launcher that masks devices per rank gives
+    # every rank local index 0, and without bus ids that cannot be told from ranks sharing one GPU)
+    buses_known = all(b is not None and b >= 0 for b in ev.get("pci_bus_ids", [-1]))
+    if ev.get("ranks_seen") != world or (ev.get("distinct_devices") != world and
+                                         (buses_known or "pci_bus_ids" not in ev)):
         raise SystemExit(f"bench: --gpus {world} but the collectives saw {ev.get('ranks_seen')} ranks on "
                          f"{ev.get('distinct_devices')} distinct devices: {ev}")
 

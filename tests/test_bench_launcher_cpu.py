@@ -88,3 +88,7 @@ def test_check_collective_evidence_rules():
         D.check_collective_evidence(dict(rccl, distinct_devices=7), 8)
     with pytest.raises(SystemExit):
         D.check_collective_evidence(dict(rccl, ranks_seen=4), 8)
+    # device masking per rank (every local index 0) without bus ids is not conclusive: no exit; with bus ids it is
+    D.check_collective_evidence(dict(rccl, distinct_devices=1, devices=[0] * 8, pci_bus_ids=[-1] * 8), 8)
+    with pytest.raises(SystemExit):
+        D.check_collective_evidence(dict(rccl, distinct_devices=1, devices=[0] * 8, pci_bus_ids=[5] * 8), 8)

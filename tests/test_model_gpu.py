@@ -124,7 +124,9 @@ def test_tiny_model_peaky_logits_vs_reference_golden(golden):
               f"{ref_pred.abs().max().item():.2f}), vectors (rel.) {errs}, output-space maps {e_hm:.3e}")
         assert e_pred < 3e-2 * max(ref_pred.abs().max().item(), 1.0)
         assert all(v < 2e-2 for v in errs.values()), errs
-        assert e_hm < 1.5e-2     # (std-1 tiny test: 3e-3; a peaky row passes v's and P's 2^-9 on unaveraged)
+        # measured on MI355X: 1.8e-3 with half-precision q / k, 4.2e-3 with bf16 (std-1 tiny test: < 3e-3 allowed); a
+        # peaky row passes v's and P's 2^-9 on unaveraged, and the dict route carries bf16 vectors on both sides
+        assert e_hm < 6.3e-3
 
 
 def test_tiny_stop_after_multimodal_and_fused_heatmaps():
