@@ -41,10 +41,10 @@ class GemmProblem(C.Structure):
 class AttnProblem(C.Structure):
     _fields_ = [("q", C.c_void_p), ("out", C.c_void_p), ("k0", C.c_void_p), ("v0", C.c_void_p),
                 ("k1", C.c_void_p), ("v1", C.c_void_p), ("out_f32", C.c_void_p),
-                ("q1", C.c_void_p), ("out1", C.c_void_p),
+                ("q1", C.c_void_p), ("out1", C.c_void_p), ("hm_con", C.c_void_p), ("hm_part", C.c_void_p),
                 ("nq", C.c_int32), ("n0", C.c_int32), ("n1", C.c_int32),
                 ("ldq", C.c_int32), ("ldo", C.c_int32), ("ldkv", C.c_int32), ("ldo32", C.c_int32),
-                ("nq0", C.c_int32), ("_pad", C.c_int32 * 3)]
+                ("nq0", C.c_int32), ("hm_C", C.c_int32), ("ldhc", C.c_int32), ("_pad", C.c_int32)]
 
 
 class HeatmapProblem(C.Structure):

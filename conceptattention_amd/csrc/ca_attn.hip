@@ -423,6 +423,14 @@ static int ca_attn_fwd_impl(const ca_attn_problem *problems, int32_t n_problems,
       ca_set_error("ca_attn_fwd_bf16[%d]: row strides must be >= num_heads*128 and multiples of 8", i);
       return CA_ERR_ARG;
     }
+    if (p.hm_con || p.hm_part) {
+      if (!p.hm_con || !p.hm_part || p.hm_C < 1 || p.hm_C > 8 || p.ldhc % 4 || p.ldhc < num_heads * 128 ||
+          (((uintptr_t)p.hm_con | (uintptr_t)p.hm_part) & 15) || !use4 || p.nq0 <= 0 || p.nq0 >= p.nq) {
+        ca_set_error("ca_attn_fwd_bf16[%d]: hm_con / hm_part need each other, 1 <= hm_C <= 8, ldhc >= num_heads*128 (%% 4), "
+                     "16-byte alignment, two query segments and the pre-scaled-q kernel", i);
+        return CA_ERR_ARG;
+      }
+    }
     if (p.out_f32 && (p.ldo32 % 4 || p.ldo32 < num_heads * 128)) {
       ca_set_error("ca_attn_fwd_bf16[%d]: ldo32 must be >= num_heads*128 and a multiple of 4", i);
       return CA_ERR_ARG;

@@ -662,6 +662,47 @@ struct HeatmapLaunch {
 };
 constexpr int HM_PRE = 6;  // 512-element chunks of a row requested ahead (dim <= 3072 in one go)
 
+// the weighting of one patch's C logits and the update of the problem's accumulators (shared by both bodies below)
+template <int CC>
+__device__ __forceinline__ void hm_weight_and_accumulate(const ca_heatmap_problem &P, const float (&z)[CC], int pp, int L,
+                                                         int C, int norm) {
+  float v[CC];
+  if (P.logits) {
+#pragma unroll
+    for (int c = 0; c < CC; ++c)
+      if (c < C) P.logits[(size_t)c * L + pp] = z[c];
+  }
+  if (norm == CA_NORM_SOFTMAX) {
+    float sum;
+    hm_softmax_terms<CC>(z, C, v, sum);
+    if (P.acc) {
+      const float inv = P.weight / sum;
+#pragma unroll
+      for (int c = 0; c < CC; ++c)
+        if (c < C) P.acc[(size_t)c * L + pp] += v[c] * inv;
+    }
+    if (P.acc2) {
+      const float inv = P.weight2 / sum;
+#pragma unroll
+      for (int c = 0; c < CC; ++c)
+        if (c < C) P.acc2[(size_t)c * L + pp] += v[c] * inv;
+    }
+  } else {
+    if (norm == CA_NORM_SPARSEMAX) hm_sparse_terms<CC, false>(z, C, v);
+    else hm_sparse_terms<CC, true>(z, C, v);
+    if (P.acc) {
+#pragma unroll
+      for (int c = 0; c < CC; ++c)
+        if (c < C) P.acc[(size_t)c * L + pp] += P.weight * v[c];
+    }
+    if (P.acc2) {
+#pragma unroll
+      for (int c = 0; c < CC; ++c)
+        if (c < C) P.acc2[(size_t)c * L + pp] += P.weight2 * v[c];
+    }
+  }
+}
+
 template <int CC, typename IT>
 __device__ __forceinline__ void heatmap_fused_body(const ca_heatmap_problem &P, int L, int C, int dim, int norm,
                                                    const float *cs) {
@@ -723,44 +764,38 @@ __device__ __forceinline__ void heatmap_fused_body(const ca_heatmap_problem &P, 
     }
     const int pp = p + lane;
     if (lane < 2 && pp < L) {
-      float z[CC], v[CC];
+      float z[CC];
 #pragma unroll
       for (int c = 0; c < CC; ++c) z[c] = lane ? acc1[c] : acc0[c];
-      if (P.logits) {
+      hm_weight_and_accumulate<CC>(P, z, pp, L, C, norm);
+    }
+  }
+}
+
+// img_f32 = 2: the logits of a patch are the sum over the heads (in head order) of the partial logits an attention launch
+// left in ca_attn_problem.hm_part ([heads][L][8] fp32); one thread per patch, 32 bytes per head and thread, coalesced
+// over the patches.  Nothing of the image vectors is read: the dot products were formed from the attention kernel's
+// accumulators.
+template <int CC>
+__device__ __forceinline__ void heatmap_part_body(const ca_heatmap_problem &P, int L, int C, int norm) {
+  const float *part = (const float *)P.img_vec;
+  const int heads = P.ldi;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < L; p += gridDim.x * blockDim.x) {
+    float z[CC];
 #pragma unroll
-        for (int c = 0; c < CC; ++c)
-          if (c < C) P.logits[(size_t)c * L + pp] = z[c];
-      }
-      if (norm == CA_NORM_SOFTMAX) {
-        float sum;
-        hm_softmax_terms<CC>(z, C, v, sum);
-        if (P.acc) {
-          const float inv = P.weight / sum;
+    for (int c = 0; c < CC; ++c) z[c] = 0.f;
+    for (int hd = 0; hd < heads; ++hd) {
+      const float *q = part + ((size_t)hd * L + p) * 8;
+      const f32x4 a = *(const f32x4 *)q;
 #pragma unroll
-          for (int c = 0; c < CC; ++c)
-            if (c < C) P.acc[(size_t)c * L + pp] += v[c] * inv;
-        }
-        if (P.acc2) {
-          const float inv = P.weight2 / sum;
+      for (int c = 0; c < 4 && c < CC; ++c) z[c] = z[c] + a[c];
+      if constexpr (CC > 4) {
+        const f32x4 b = *(const f32x4 *)(q + 4);
 #pragma unroll
-          for (int c = 0; c < CC; ++c)
-            if (c < C) P.acc2[(size_t)c * L + pp] += v[c] * inv;
-        }
-      } else {
-        if (norm == CA_NORM_SPARSEMAX) hm_sparse_terms<CC, false>(z, C, v);
-        else hm_sparse_terms<CC, true>(z, C, v);
-        if (P.acc) {
-#pragma unroll
-          for (int c = 0; c < CC; ++c)
-            if (c < C) P.acc[(size_t)c * L + pp] += P.weight * v[c];
-        }
-        if (P.acc2) {
-#pragma unroll
-          for (int c = 0; c < CC; ++c)
-            if (c < C) P.acc2[(size_t)c * L + pp] += P.weight2 * v[c];
-        }
+        for (int c = 4; c < CC; ++c) z[c] = z[c] + b[c - 4];
       }
     }
+    hm_weight_and_accumulate<CC>(P, z, p, L, C, norm);
   }
 }
 
@@ -770,6 +805,10 @@ __global__ __launch_bounds__(CC <= 4 ? 256 : 512) void ca_heatmap_fused_kernel(H
   float *cs = (float *)smem_raw;  // [CC][dim]: rows >= C repeat row C - 1 (their logits are never used)
   const ca_heatmap_problem &P = A.p[blockIdx.y];
   const int dim = A.dim, C = A.C;
+  if (P.img_f32 == 2) {   // (workgroup-uniform: a problem of partial logits reads no vectors at all)
+    heatmap_part_body<CC>(P, A.L, C, A.norm);
+    return;
+  }
   for (int c = 0; c < CC; ++c) {
     const int cr = min(c, C - 1);
     for (int k = threadIdx.x * 4; k < dim; k += blockDim.x * 4) {
@@ -1143,10 +1182,12 @@ extern "C" int ca_heatmap_fused(const ca_heatmap_problem *problems, int32_t n_pr
   A.L = L, A.C = C, A.dim = dim, A.norm = norm;
   for (int i = 0; i < n_problems; ++i) {
     const ca_heatmap_problem &p = problems[i];
-    if (!p.img_vec || !p.con_vec || (!p.acc && !p.acc2 && !p.logits) || p.ldi < dim || p.ldc < dim ||
-        p.ldi % (p.img_f32 ? 4 : 8) || p.ldc % 4 || (p.img_f32 & ~1) || (p.con_f32 & ~1) ||
-        (((uintptr_t)p.img_vec | (uintptr_t)p.con_vec) & 15) ||
-        (((uintptr_t)p.acc | (uintptr_t)p.acc2 | (uintptr_t)p.logits) & 3)) {
+    const bool part = p.img_f32 == 2;   // per-head partial logits [ldi heads][L][8] instead of vectors
+    if (!p.img_vec || (!p.acc && !p.acc2 && !p.logits) || ((uintptr_t)p.img_vec & 15) ||
+        (((uintptr_t)p.acc | (uintptr_t)p.acc2 | (uintptr_t)p.logits) & 3) || p.img_f32 < 0 || p.img_f32 > 2 ||
+        (part ? (p.ldi < 1 || p.ldi > 1024)
+              : (!p.con_vec || p.ldi < dim || p.ldc < dim || p.ldi % (p.img_f32 ? 4 : 8) || p.ldc % 4 ||
+                 (p.con_f32 & ~1) || ((uintptr_t)p.con_vec & 15)))) {
       ca_set_error("ca_heatmap_fused: problem %d invalid (ldi=%d ldc=%d img_f32=%d con_f32=%d; vectors 16-byte aligned, "
                    "at least one of acc / acc2 / logits)", i, p.ldi, p.ldc, p.img_f32, p.con_f32);
       return CA_ERR_ARG;

@@ -251,11 +251,20 @@ class HipFluxDiT:
         # carry k's bf16 rounding again (measured in the same test file).
         self.capture_independent_image = False
         self._layer_indep = False   # (set per layer by _double_block, read by _capture)
+        self._layer_part = False
         # fp8 mode: the qkv projection of a layer whose maps are requested stays bf16 (_double_block)
         self.fp8_bf16_qkv_when_captured = os.environ.get("CA_FP8_QKV_BF16_CAPTURED", "1") != "0"
         # the heat-map updates of a captured layer (all work items, both spaces) as ONE ca_heatmap_fused launch; False =
         # logits + weighting launches per item and space (the same bits; parity / A-B aid, and what C > 8 uses)
         self.fused_heatmaps = True
+        # (round 5) The output-space logits of a captured layer from the attention kernel's own accumulators: the concept
+        # problems run first (their fp32 rows ATT32 must exist), every main problem's epilogue then forms, per head, the
+        # dot products of its image rows (fp32, before their bf16 rounding) with the C concept rows and leaves
+        # [heads, L, 8] partial logits (PART, 3 MB per item), which ca_heatmap_fused sums over the heads -- instead of an
+        # fp32 copy of every [text | image] row (ATTI32: 53 MB per item, +115 us per captured 5-item attention launch,
+        # and 250 MB of reads in the heat-map launch).  The same arithmetic in another summation order (per head, then
+        # over the heads).  False = the fp32 rows (rounds 3-4; A/B aid).  Needs fused_heatmaps and the pre-scaled-q kernel.
+        self.epilogue_logits = True
         if self.qk_f16 not in ("all", "captured", "0"):
             raise ValueError("CA_QK_F16 must be all, captured or 0")
         self.set_precision(precision)
@@ -354,6 +363,8 @@ class HipFluxDiT:
         "ATTI32": lambda n, B, T, L, H: ((B, T + L, H), torch.float32),   # fp32 [text | image] attention rows
         # capture_independent_image: the accurate q of the captured layers' image / concept rows (the map-side attention
         # problems' queries) and those problems' bf16 output rows, which nothing but the heat maps reads
+        # epilogue_logits: per-head partial output-space logits of every item's image rows [B, heads, L, 8]
+        "PART": lambda n, B, T, L, H: ((B, H // 128, L, 8), torch.float32),
         "QACC": lambda n, B, T, L, H: ((n, H), torch.bfloat16),
         "ATTM": lambda n, B, T, L, H: ((n, H), torch.bfloat16),
     }
@@ -371,6 +382,7 @@ class HipFluxDiT:
     XML = property(lambda self: self._lazy_buffer("XML"))
     QD = property(lambda self: self._lazy_buffer("QD"))
     ATTI32 = property(lambda self: self._lazy_buffer("ATTI32"))
+    PART = property(lambda self: self._lazy_buffer("PART"))
     QACC = property(lambda self: self._lazy_buffer("QACC"))
     ATTM = property(lambda self: self._lazy_buffer("ATTM"))
 
@@ -766,6 +778,12 @@ class HipFluxDiT:
             qkv_launch()
         # K8+K9: per item, joint text+image attention and the concept rows; one launch (concept problems first)
         f32img = self._f32_image_vectors(capture, heatmaps)
+        # per-head partial logits from the attention epilogue instead of fp32 rows (self.epilogue_logits above)
+        use_part = bool(capture and heatmaps is not None and not indep and self.epilogue_logits and self.fused_heatmaps
+                        and self.prescale_q and 1 <= C <= 8 and ops.heatmap_fused_fits(C, H))
+        self._layer_part = use_part
+        if use_part:
+            f32img = False
 
         def concept_problem(j, q_rows, out_rows, out32):
             cj, ij = slice(j * C, (j + 1) * C), slice(oI + j * Li, oI + (j + 1) * Li)
@@ -781,10 +799,15 @@ class HipFluxDiT:
         if C > 0 and not (cross or self_):   # :157-159 concept_attn = concept_v
             ATT[:oT].copy_(vs[:oT])
             self.ATT32[:oT].copy_(vs[:oT])
+        if use_part and probs:
+            # the concept rows first, in their own launch: the main problems' epilogues read ATT32
+            ops.attention(probs, NH, q_prescaled=self.prescale_q, qk_f16=qk16)
+            probs = []
         for j in range(B):
             tj, ij = slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)
+            hm_kw = dict(hm_con=self.ATT32[j * C:(j + 1) * C], hm_part=self.PART[j]) if use_part else {}
             probs.append(ops.Attn(qs[tj], ATT[tj], ks[tj], vs[tj], ks[ij], vs[ij], q1=qs[ij], out1=ATT[ij],
-                                  out_f32=self.ATTI32[j] if (f32img and not indep) else None))
+                                  out_f32=self.ATTI32[j] if (f32img and not indep) else None, **hm_kw))
         if indep:
             # the maps' side: the accurate q of the image rows against the same keys / values, into rows that only the
             # heat maps read (one more problem per item in this launch) ...
@@ -884,15 +907,18 @@ class HipFluxDiT:
             # is the dominant heat-map error otherwise -- DESIGN.md "tolerance")
             li = hm.layer_indices.index(layer)
             cj, ij = slice(j * C, (j + 1) * C), slice(oI + j * Li, oI + (j + 1) * Li)
-            img_out = self.ATTI32[j, g.T:] if self._f32_image_vectors(True, heatmaps) else \
-                (self.ATTM[ij] if self._layer_indep else ATT[ij])   # (_layer_indep: set by _double_block for this layer)
+            part = self._layer_part   # (_layer_part / _layer_indep: set by _double_block for this layer)
+            img_out = None if part else (self.ATTI32[j, g.T:] if self._f32_image_vectors(True, heatmaps) else
+                                         (self.ATTM[ij] if self._layer_indep else ATT[ij]))
             for img_vec, con_vec, acc, table in ((img_out, self.ATT32[cj], hm.out_space, hm.per_layer_out),
                                                  (QPRE[ij], QPRE[cj], hm.cross_space, hm.per_layer_cross)):
                 if acc is None and table is None:
                     continue
                 if fused:
                     launches.setdefault(hm.norm, []).append(ops.Heatmap(
-                        img_vec, con_vec, acc, hm.weight, None if table is None else table[li], hm.per_layer_weight))
+                        img_vec, None if img_vec is None else con_vec, acc, hm.weight,
+                        None if table is None else table[li], hm.per_layer_weight,
+                        part=self.PART[j] if img_vec is None else None))
                     continue
                 # the three-launch form (more than 8 concepts, or fused_heatmaps = False: the A/B and parity aid)
                 ops.heatmap_logits(img_vec, con_vec, self.LOGITS[:C])

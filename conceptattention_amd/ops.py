@@ -183,6 +183,10 @@ class Attn:
     out_f32: Optional[torch.Tensor] = None  # optional fp32 copy of the output rows
     q1: Optional[torch.Tensor] = None       # second query-row segment (its rows follow q's) and its output rows
     out1: Optional[torch.Tensor] = None
+    # per-head partial heat-map logits of the second segment's rows (q_prescaled kernels): hm_con fp32 [C <= 8, heads*128]
+    # = the concept rows' attention outputs (complete before this launch), hm_part fp32 [heads, rows of q1, 8]
+    hm_con: Optional[torch.Tensor] = None
+    hm_part: Optional[torch.Tensor] = None
 
 
 def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] = None,
@@ -212,6 +216,16 @@ def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] =
             if a.k1.stride(0) != p.ldkv or a.v1.stride(0) != p.ldkv or a.v1.shape[0] != a.k1.shape[0]:
                 raise ValueError(f"attention[{i}]: both key/value segments must share one row stride")
             p.k1, p.v1, p.n1 = a.k1.data_ptr(), a.v1.data_ptr(), a.k1.shape[0]
+        if a.hm_con is not None or a.hm_part is not None:
+            if a.hm_con is None or a.hm_part is None or a.q1 is None:
+                raise ValueError(f"attention[{i}]: hm_con, hm_part and a second query segment go together")
+            _chk(a.hm_con, torch.float32, "hm_con"), _chk(a.hm_part, torch.float32, "hm_part")
+            if a.hm_con.dim() != 2 or a.hm_con.shape[1] != num_heads * 128 or not 1 <= a.hm_con.shape[0] <= 8 or \
+                    tuple(a.hm_part.shape) != (num_heads, a.q1.shape[0], 8) or not a.hm_part.is_contiguous():
+                raise ValueError(f"attention[{i}]: hm_con must be fp32 [C <= 8, heads*128], hm_part contiguous fp32 "
+                                 "[heads, rows of q1, 8]")
+            p.hm_con, p.hm_part = a.hm_con.data_ptr(), a.hm_part.data_ptr()
+            p.hm_C, p.ldhc = a.hm_con.shape[0], a.hm_con.stride(0)
         if a.out_f32 is not None:
             _chk(a.out_f32, torch.float32, "out_f32")
             if a.out_f32.shape[0] != p.nq:
@@ -454,13 +468,16 @@ class Heatmap:
     """One (work item, space) problem of a fused heat-map launch: logits = img_vec @ con_vec.T per patch, then
     acc += weight * norm_c(logits) and / or acc2 += weight2 * norm_c(logits); ``logits`` (optional) receives the raw
     logits.  img_vec bf16|fp32 [L,dim], con_vec bf16|fp32 [C,dim], acc / acc2 / logits fp32 [C,L] contiguous."""
-    img_vec: torch.Tensor
-    con_vec: torch.Tensor
+    img_vec: Optional[torch.Tensor]
+    con_vec: Optional[torch.Tensor]
     acc: Optional[torch.Tensor] = None
     weight: float = 0.0
     acc2: Optional[torch.Tensor] = None
     weight2: float = 0.0
     logits: Optional[torch.Tensor] = None
+    # instead of the two vector sets: fp32 [heads, L, 8] per-head partial logits (Attn.hm_part): logits = their sum over
+    # the heads, in head order
+    part: Optional[torch.Tensor] = None
 
 
 def heatmap_fused_fits(C: int, dim: int) -> bool:
@@ -475,16 +492,27 @@ def heatmap_fused(problems: Sequence[Heatmap], norm: int = L.NORM_SOFTMAX) -> No
     if not 1 <= len(problems) <= L.HEATMAP_MAX_PROBLEMS:
         raise ValueError(f"heatmap_fused: 1..{L.HEATMAP_MAX_PROBLEMS} problems per launch")
     arr = (L.HeatmapProblem * len(problems))()
-    Lp, dim, Cc = problems[0].img_vec.shape[0], problems[0].img_vec.shape[1], problems[0].con_vec.shape[0]
+    some = next((t for h in problems for t in (h.acc, h.acc2, h.logits) if t is not None), None)
+    if some is None:
+        raise ValueError("heatmap_fused: every problem needs acc, acc2 or logits")
+    Cc, Lp = some.shape
+    vec = next((h for h in problems if h.part is None), None)
+    dim = 8 if vec is None else vec.img_vec.shape[1]
     for i, h in enumerate(problems):
-        if h.img_vec.dtype not in (torch.bfloat16, torch.float32) or h.con_vec.dtype not in (torch.bfloat16, torch.float32):
-            raise ValueError(f"heatmap_fused[{i}]: img_vec and con_vec must be bf16 or fp32")
-        _chk(h.img_vec, h.img_vec.dtype, "img_vec"), _chk(h.con_vec, h.con_vec.dtype, "con_vec")
-        if tuple(h.img_vec.shape) != (Lp, dim) or tuple(h.con_vec.shape) != (Cc, dim):
-            raise ValueError(f"heatmap_fused[{i}]: all problems of a launch share L, C and dim")
         p = arr[i]
-        p.img_vec, p.con_vec, p.ldi, p.ldc = h.img_vec.data_ptr(), h.con_vec.data_ptr(), h.img_vec.stride(0), h.con_vec.stride(0)
-        p.img_f32, p.con_f32 = int(h.img_vec.dtype == torch.float32), int(h.con_vec.dtype == torch.float32)
+        if h.part is not None:
+            _chk(h.part, torch.float32, "part")
+            if h.part.dim() != 3 or tuple(h.part.shape[1:]) != (Lp, 8) or not h.part.is_contiguous():
+                raise ValueError(f"heatmap_fused[{i}]: part must be contiguous fp32 [heads, L, 8]")
+            p.img_vec, p.ldi, p.img_f32 = h.part.data_ptr(), h.part.shape[0], 2
+        else:
+            if h.img_vec.dtype not in (torch.bfloat16, torch.float32) or h.con_vec.dtype not in (torch.bfloat16, torch.float32):
+                raise ValueError(f"heatmap_fused[{i}]: img_vec and con_vec must be bf16 or fp32")
+            _chk(h.img_vec, h.img_vec.dtype, "img_vec"), _chk(h.con_vec, h.con_vec.dtype, "con_vec")
+            if tuple(h.img_vec.shape) != (Lp, dim) or tuple(h.con_vec.shape) != (Cc, dim):
+                raise ValueError(f"heatmap_fused[{i}]: all problems of a launch share L, C and dim")
+            p.img_vec, p.con_vec, p.ldi, p.ldc = h.img_vec.data_ptr(), h.con_vec.data_ptr(), h.img_vec.stride(0), h.con_vec.stride(0)
+            p.img_f32, p.con_f32 = int(h.img_vec.dtype == torch.float32), int(h.con_vec.dtype == torch.float32)
         for name in ("acc", "acc2", "logits"):
             t = getattr(h, name)
             if t is not None:

@@ -166,10 +166,21 @@ typedef struct {
                      (concept_attention_pipeline.py:57-62) see neither side's bf16 rounding */
   const void *q1; /* second query segment (rows nq0..nq-1), row stride ldq; or NULL */
   void *out1;     /* its output rows, row stride ldo */
+  const float *hm_con; /* (round 5; pre-scaled-q kernels only) optional fp32 [hm_C, heads*128], row stride ldhc: the C   */
+                       /* concept rows' attention outputs of this work item, complete BEFORE this launch starts        */
+  float *hm_part;      /* with hm_con: fp32 [heads][nq - nq0][8] -- per head the partial output-space heat-map logits  */
+                       /* of the second query segment's rows (the image rows):                                         */
+                       /*   hm_part[(head * (nq - nq0) + r) * 8 + c] = <out row nq0 + r of that head, in fp32 before   */
+                       /*   its rounding to bf16, hm_con[c, head*128 ..]>                                              */
+                       /* i.e. the dot products of concept_attention_pipeline.py:57-61 split by head, formed from the  */
+                       /* accumulators instead of an fp32 copy of every row (out_f32: 53 MB per item); summed over the */
+                       /* heads and weighted by ca_heatmap_fused (img_f32 = 2)                                         */
   int32_t nq, n0, n1;
   int32_t ldq, ldo, ldkv, ldo32;
   int32_t nq0;    /* query rows in the first segment; 0 or nq = all */
-  int32_t _pad[3];
+  int32_t hm_C;   /* concepts in hm_con (1..8) */
+  int32_t ldhc;   /* row stride of hm_con (elements, % 4 == 0) */
+  int32_t _pad;
 } ca_attn_problem;
 
 /* scale = the softmax scale (1/sqrt(128) at the reference's call sites), or CA_ATTN_Q_PRESCALED when the q rows were
@@ -308,7 +319,10 @@ int ca_heatmap_norm_accumulate(const float *logits, int32_t C, int32_t L, int32_
  * CA_ERR_ARG otherwise (the caller then uses the three-launch form). */
 #define CA_HEATMAP_MAX_PROBLEMS 16
 typedef struct {
-  const void *img_vec; /* [L, dim] bf16, or fp32 if img_f32; row stride ldi elements (% 8 bf16, % 4 fp32) */
+  const void *img_vec; /* [L, dim] bf16, or fp32 if img_f32 = 1; row stride ldi elements (% 8 bf16, % 4 fp32).        */
+                       /* img_f32 = 2: instead fp32 [ldi heads][L][8], the per-head partial logits an attention       */
+                       /* launch left in ca_attn_problem.hm_part: logits[c,p] = their sum over the heads in head      */
+                       /* order; con_vec is then unused (may be NULL)                                                 */
   const void *con_vec; /* [C, dim] bf16, or fp32 if con_f32; row stride ldc elements */
   float *acc;          /* fp32 [C, L] contiguous, or NULL */
   float *acc2;         /* fp32 [C, L] contiguous, or NULL */

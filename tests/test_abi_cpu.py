@@ -35,7 +35,7 @@ def test_version_and_error_string(lib):
 def test_struct_layouts_match_header():
     # sizes the C compiler sees (LP64): pointers 8, int32 4, no implicit padding inside
     assert ctypes.sizeof(L.GemmProblem) == 14 * 8 + 20 * 4   # 16 int32 + qpre_f32 + float q_out_scale + qk_f16 + pad
-    assert ctypes.sizeof(L.AttnProblem) == 9 * 8 + 8 * 4 + 3 * 4 + 4  # trailing pad to 8-byte alignment
+    assert ctypes.sizeof(L.AttnProblem) == 11 * 8 + 11 * 4 + 4  # (hm_con / hm_part since round 5) trailing pad to 8 bytes
     assert ctypes.sizeof(L.ModSegment) == 24 and ctypes.sizeof(L.NormSegment) == 24
     assert ctypes.sizeof(L.HeatmapProblem) == 5 * 8 + 4 * 4 + 2 * 4   # ca_heatmap_problem: 64 bytes
 
@@ -67,6 +67,12 @@ def test_binding_fields_match_header_field_for_field():
     hdr = _header_struct_fields("ca_gemm_problem")
     assert [f for _, f in hdr] == [f for f, _ in L.GemmProblem._fields_]
     assert [_CT[t] for t, _ in hdr] == [t for _, t in L.GemmProblem._fields_]
+
+
+def test_attn_problem_fields_match_header():
+    hdr = _header_struct_fields("ca_attn_problem")
+    assert [f for _, f in hdr] == [f for f, _ in L.AttnProblem._fields_]
+    assert [_CT[t] for t, _ in hdr] == [t for _, t in L.AttnProblem._fields_]
 
 
 def test_heatmap_problem_fields_match_header_and_arguments_are_checked_without_a_gpu(lib):

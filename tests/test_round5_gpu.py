@@ -178,3 +178,76 @@ def test_heatmap_fused_shape_fuzz():
         for h, (r_acc, r_acc2) in zip(probs, refs):
             assert torch.equal(h.acc, r_acc), (case, C, Lp, dim, norm)
             assert r_acc2 is None or torch.equal(h.acc2, r_acc2), (case, C, Lp, dim, norm)
+
+
+@pytest.mark.parametrize("qk_f16", [False, True])
+@pytest.mark.parametrize("T,Limg,C,NH", [(64, 300, 4, 3), (8, 256, 1, 2), (256, 700, 8, 24)])
+def test_attention_epilogue_partial_logits(T, Limg, C, NH, qk_f16):
+    """ca_attn_problem.hm_con / hm_part: per head the dot products of the second query segment's rows (the fp32
+    accumulators, before their bf16 rounding) with the C concept rows, against an fp32 attention of the same bf16 inputs;
+    summed over the heads by ca_heatmap_fused (img_f32 = 2) they are the logits the vector form computes from fp32 rows.
+    Rows of the first segment and rows past the problem leave nothing; the bf16 outputs are untouched by the feature."""
+    H = NH * 128
+    n = T + Limg
+    g = torch.Generator(device="cpu").manual_seed(T + Limg)
+    q = (torch.randn(n, H, generator=g) * 0.35).to(DEV)
+    k = torch.randn(n, H, generator=g).to(DEV)
+    v = torch.randn(n, H, generator=g).to(DEV)
+    con = (torch.randn(C, H, generator=g) * 0.5).to(DEV)
+    cast = (lambda t: t.half().view(torch.bfloat16)) if qk_f16 else (lambda t: t.bfloat16())
+    back = (lambda t: t.view(torch.float16).float()) if qk_f16 else (lambda t: t.float())
+    qb, kb, vb = cast(q), cast(k), v.bfloat16()
+    out = torch.zeros(n, H, device=DEV, dtype=torch.bfloat16)
+    out_plain = torch.zeros_like(out)
+    part = torch.full((NH, Limg, 8), -7.0, device=DEV)
+    ops.attention([ops.Attn(qb[:T], out[:T], kb[:T], vb[:T], kb[T:], vb[T:], q1=qb[T:], out1=out[T:], hm_con=con,
+                            hm_part=part)], NH, q_prescaled=True, qk_f16=qk_f16)
+    ops.attention([ops.Attn(qb[:T], out_plain[:T], kb[:T], vb[:T], kb[T:], vb[T:], q1=qb[T:], out1=out_plain[T:])], NH,
+                  q_prescaled=True, qk_f16=qk_f16)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_plain)
+    qf, kf, vf = back(qb).view(n, NH, 128), back(kb).view(n, NH, 128), vb.float().view(n, NH, 128)
+    s = torch.einsum("qhd,khd->hqk", qf, kf)                                  # q carries softmax_scale * log2(e)
+    pr = torch.exp2(s - s.max(-1, keepdim=True).values)
+    o = torch.einsum("hqk,khd->qhd", pr / pr.sum(-1, keepdim=True), vf)      # fp32 attention of the same inputs
+    ref = torch.einsum("qhd,chd->hqc", o[T:], con.view(C, NH, 128))           # [heads, image rows, C]
+    assert torch.all(part[:, :, C:] == -7.0)                                  # columns past C are not written
+    err = (part[:, :, :C] - ref).abs().max().item()
+    assert err < 6e-3 * max(1.0, ref.abs().max().item()), (err, ref.abs().max().item())   # P is bf16 inside the kernel
+    # summed over the heads by the heat-map launch == the vector form on the fp32 rows, to fp32 summation order
+    acc_p, acc_v = torch.zeros(C, Limg, device=DEV), torch.zeros(C, Limg, device=DEV)
+    lg_p, lg_v = torch.zeros(C, Limg, device=DEV), torch.zeros(C, Limg, device=DEV)
+    o32 = torch.zeros(n, H, device=DEV)
+    ops.attention([ops.Attn(qb[:T], out_plain[:T], kb[:T], vb[:T], kb[T:], vb[T:], q1=qb[T:], out1=out_plain[T:],
+                            out_f32=o32)], NH, q_prescaled=True, qk_f16=qk_f16)
+    ops.heatmap_fused([ops.Heatmap(None, None, acc_p, 1.0, logits=lg_p, part=part),
+                       ops.Heatmap(o32[T:], con, acc_v, 1.0, logits=lg_v)])
+    torch.cuda.synchronize()
+    assert (lg_p - lg_v).abs().max().item() < 2e-5 * max(1.0, lg_v.abs().max().item())
+    assert (acc_p - acc_v).abs().max().item() < 2e-5
+    with pytest.raises(ValueError):   # the old kernel (a softmax scale passed) does not have the feature
+        ops.attention([ops.Attn(qb[:T], out[:T], kb[:T], vb[:T], kb[T:], vb[T:], q1=qb[T:], out1=out[T:], hm_con=con,
+                                hm_part=part)], NH, scale=0.088)
+
+
+def test_model_epilogue_logits_equal_the_fp32_row_route():
+    """HipFluxDiT.epilogue_logits (the output-space logits from the attention kernel's accumulators, per head) against
+    the fp32-rows route it replaces (ATTI32): same arithmetic, another summation order -- maps within 2e-6; the cross
+    space, the streams and the latent do not change by one bit."""
+    from conceptattention_amd.flux_dit import HeatmapRequest
+    B, C, Lp = 3, 3, 256
+    m, p, kw = _tiny_forward_kwargs(B)
+    kw = dict(kw, stop_after_multimodal_attentions=False)
+    res = {}
+    for on in (True, False):
+        m.epilogue_logits = on
+        acc = torch.zeros(B, 2, C, Lp, device=DEV)
+        reqs = [HeatmapRequest(tuple(range(p.depth)), 0.5, acc[j, 0], acc[j, 1]) for j in range(B)]
+        pred, _ = m(heatmaps=reqs, **kw)
+        torch.cuda.synchronize()
+        res[on] = (acc, pred)
+    assert torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][0][:, 1], res[False][0][:, 1])
+    d = (res[True][0][:, 0] - res[False][0][:, 0]).abs().max().item()
+    assert 0 <= d < 2e-6, d
+    m.epilogue_logits = True
