@@ -93,6 +93,7 @@ def test_model_fused_heatmaps_equal_the_three_launch_form_and_shared_accumulator
     from conceptattention_amd.flux_dit import HeatmapRequest
     B, C, Lp = 3, 3, 256
     m, p, kw = _tiny_forward_kwargs(B)
+    m.epilogue_logits = False   # (the fp32-rows route on both sides: the accumulator route sums in another order)
     res = {}
     for fused in (True, False):
         m.fused_heatmaps = fused
