@@ -216,7 +216,8 @@ class HipFluxDiT:
         # attention launch, 53 MB per item): layer 0's map moves by 2e-5 (tests/tools/diag_out_space.py), but deeper
         # layers do not agree -- without it the worst step-0 map is 8.1e-4 (layer 4) instead of 3.8e-4 and the final
         # maps 1.45e-4 instead of 7.9e-5 from the fp32 oracle (tests/test_full_depth_gpu.py fails its 1.5 x bounds).
-        # Kept on; "0" = the bf16 rows (A/B aid).
+        # So the fp32 precision stays -- but since round 5 without the copy: epilogue_logits (below) forms the logits from
+        # the attention kernel's accumulators; this switch only matters with epilogue_logits = False ("0" = the bf16 rows).
         self.f32_image_vectors = os.environ.get("CA_F32_IMAGE_VECTORS", "1") != "0"
         # The cross-attention-space vectors (post-QKNorm, pre-RoPE q) of the captured layers from the UNROUNDED
         # LayerNorm output: the bf16 rounding of that GEMM operand is ~90 % of the cross-space heat-map error
