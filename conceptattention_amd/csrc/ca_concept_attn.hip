@@ -6,6 +6,8 @@
 // tiny kernel merges the per-chunk softmax partials.  q carries softmax_scale * log2(e) (CA_ATTN_Q_PRESCALED), q / k are
 // bf16 or IEEE half (qk_f16), v is bf16.  The key -> chunk split depends on the key count only, so a problem's bits do not
 // depend on the launch it shares.
+#include <type_traits>
+
 #include "ca_common.h"
 
 namespace {
@@ -31,6 +33,19 @@ __device__ __forceinline__ void decode8(const uint4 raw, bool f16, float (&out)[
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = (float)v[j];
   }
+}
+
+// sum over the 16 lanes of a DPP row (the lanes that share a key), result in every lane: two quad permutes, the half
+// mirror and the mirror -- four v_add_f32 with a DPP operand instead of four ds_bpermute round trips through LDS
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  return v;
 }
 
 // merge (m2, l2, o2) into (m, l, o): both are partial softmax states of the same row over disjoint key sets
@@ -95,10 +110,7 @@ __global__ __launch_bounds__(256) void ca_concept_attn_partial_kernel(const Conc
           float s = 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) s = __builtin_fmaf(q[c][j], kf[j], s);
-          s += __shfl_xor(s, 1);
-          s += __shfl_xor(s, 2);
-          s += __shfl_xor(s, 4);
-          s += __shfl_xor(s, 8);
+          s = row16_sum(s);
           if (!ok) s = -1e30f;
           const float mn = fmaxf(m[c], s);
           const float a = __builtin_amdgcn_exp2f(m[c] - mn), pr = ok ? __builtin_amdgcn_exp2f(s - mn) : 0.f;

@@ -239,6 +239,7 @@ def test_model_epilogue_logits_equal_the_fp32_row_route():
     B, C, Lp = 3, 3, 256
     m, p, kw = _tiny_forward_kwargs(B)
     kw = dict(kw, stop_after_multimodal_attentions=False)
+    m.concept_kernel = False   # (the concept rows on the MFMA units on both sides: the comparison is about the logits)
     res = {}
     for on in (True, False):
         m.epilogue_logits = on
@@ -251,7 +252,14 @@ def test_model_epilogue_logits_equal_the_fp32_row_route():
     assert torch.equal(res[True][0][:, 1], res[False][0][:, 1])
     d = (res[True][0][:, 0] - res[False][0][:, 0]).abs().max().item()
     assert 0 <= d < 2e-6, d
-    m.epilogue_logits = True
+    # ... and the concept rows on ca_concept_attn_fwd (fp32 probabilities) instead of the MFMA units (bf16): the image
+    # stream does not see the concept rows at all; the maps move by the MFMA units' rounding of those rows
+    m.epilogue_logits, m.concept_kernel = True, True
+    acc = torch.zeros(B, 2, C, Lp, device=DEV)
+    pred, _ = m(heatmaps=[HeatmapRequest(tuple(range(p.depth)), 0.5, acc[j, 0], acc[j, 1]) for j in range(B)], **kw)
+    assert torch.equal(pred, res[True][1])
+    dk = (acc - res[True][0]).abs().max().item()
+    assert 0 < dk < 2e-3, dk
 
 
 @pytest.mark.parametrize("qk_f16", [False, True])
