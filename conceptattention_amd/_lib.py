@@ -71,8 +71,6 @@ SIGNATURES = {
     "ca_gemm_fp8": (C.c_int, [C.POINTER(GemmProblem), C.c_int32, C.c_void_p]),
     "ca_attn_fwd_bf16": (C.c_int, [C.POINTER(AttnProblem), C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "ca_attn_fwd_qk16": (C.c_int, [C.POINTER(AttnProblem), C.c_int32, C.c_int32, C.c_void_p]),
-    "ca_concept_attn_fwd": (C.c_int, [C.POINTER(AttnProblem), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
-                                      C.c_void_p]),
     "ca_attn_stats": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int32]),
     "ca_ln_modulate_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(ModSegment), C.c_int32, C.c_float, C.c_void_p]),

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, "libconceptattn.so")
-SOURCES = ["ca_api.hip", "ca_gemm.hip", "ca_attn.hip", "ca_attn4.hip", "ca_rowops.hip", "ca_concept_attn.hip"]
+SOURCES = ["ca_api.hip", "ca_gemm.hip", "ca_attn.hip", "ca_attn4.hip", "ca_rowops.hip"]
 # ca_attn4.hip owns the AGPR file by hand (literal a[...] registers in its asm statements): hipcc must never park a
 # VGPR there (its default spill target), and the emitted code is audited for it below
 EXTRA_FLAGS = {"ca_attn4.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj"]}

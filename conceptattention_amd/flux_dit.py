@@ -266,7 +266,6 @@ class HipFluxDiT:
         # and 250 MB of reads in the heat-map launch).  The same arithmetic in another summation order (per head, then
         # over the heads).  False = the fp32 rows (rounds 3-4; A/B aid).  Needs fused_heatmaps and the pre-scaled-q kernel.
         self.epilogue_logits = True
-        self.concept_kernel = True    # (with epilogue_logits: the concept problems of a captured layer on ca_concept_attn_fwd)
         if self.qk_f16 not in ("all", "captured", "0"):
             raise ValueError("CA_QK_F16 must be all, captured or 0")
         self.set_precision(precision)
@@ -367,8 +366,6 @@ class HipFluxDiT:
         # problems' queries) and those problems' bf16 output rows, which nothing but the heat maps reads
         # epilogue_logits: per-head partial output-space logits of every item's image rows [B, heads, L, 8]
         "PART": lambda n, B, T, L, H: ((B, H // 128, L, 8), torch.float32),
-        # ca_concept_attn_fwd's scratch: per (item, head, 512-key chunk, row) a partial softmax state of 136 floats
-        "CWS": lambda n, B, T, L, H: ((B * (H // 128) * (-(-(n // B) // 512) + 1) * 8 * 136,), torch.float32),
         "QACC": lambda n, B, T, L, H: ((n, H), torch.bfloat16),
         "ATTM": lambda n, B, T, L, H: ((n, H), torch.bfloat16),
     }
@@ -387,7 +384,6 @@ class HipFluxDiT:
     QD = property(lambda self: self._lazy_buffer("QD"))
     ATTI32 = property(lambda self: self._lazy_buffer("ATTI32"))
     PART = property(lambda self: self._lazy_buffer("PART"))
-    CWS = property(lambda self: self._lazy_buffer("CWS"))
     QACC = property(lambda self: self._lazy_buffer("QACC"))
     ATTM = property(lambda self: self._lazy_buffer("ATTM"))
 
@@ -805,13 +801,10 @@ class HipFluxDiT:
             ATT[:oT].copy_(vs[:oT])
             self.ATT32[:oT].copy_(vs[:oT])
         if use_part and probs:
-            # the concept rows first, in their own launch: the main problems' epilogues read ATT32.  As MFMA units (one
-            # workgroup per head sweeping all keys for 4 of 256 query rows) that launch costs 190 us; ca_concept_attn_fwd
-            # splits the keys over workgroups and works in fp32 (self.concept_kernel = False: the MFMA units, A/B aid)
-            if self.concept_kernel:
-                ops.concept_attention(probs, NH, self.CWS, qk_f16=qk16)
-            else:
-                ops.attention(probs, NH, q_prescaled=self.prescale_q, qk_f16=qk16)
+            # the concept rows first, in their own launch (102 us for a 5-item layer): the main problems' epilogues read
+            # ATT32.  (A bandwidth-style kernel for these <= 8-row problems -- keys split over workgroups, fp32 scores --
+            # was built and measured at the same 100 us and the same maps: removed again)
+            ops.attention(probs, NH, q_prescaled=self.prescale_q, qk_f16=qk16)
             probs = []
         for j in range(B):
             tj, ij = slice(oT + j * T, oT + (j + 1) * T), slice(oI + j * Li, oI + (j + 1) * Li)

@@ -253,46 +253,6 @@ def attention(problems: Sequence[Attn], num_heads: int, scale: Optional[float] =
     launch()
 
 
-CONCEPT_ATTN_CHUNK, CONCEPT_ATTN_ROWS, CONCEPT_ATTN_PART = 512, 8, 136   # (ca_concept_attn.hip)
-
-
-def concept_attention_workspace_floats(n_problems: int, num_heads: int, max_keys: int) -> int:
-    return n_problems * num_heads * (-(-max_keys // CONCEPT_ATTN_CHUNK)) * CONCEPT_ATTN_ROWS * CONCEPT_ATTN_PART
-
-
-def concept_attention(problems: Sequence[Attn], num_heads: int, workspace: torch.Tensor, qk_f16: bool = False) -> None:
-    """Attention for problems of at most 8 query rows (the concept rows of a work item) as a bandwidth problem
-    (ca_concept_attn_fwd): keys split over workgroups, fp32 scores and probabilities.  q pre-scaled (softmax_scale *
-    log2 e); ``workspace``: fp32 scratch of at least concept_attention_workspace_floats(...) elements."""
-    lib = L.load()
-    arr = (L.AttnProblem * len(problems))()
-    for i, a in enumerate(problems):
-        for n in ("q", "out", "k0", "v0"):
-            _chk(getattr(a, n), torch.bfloat16, n)
-        p = arr[i]
-        p.q, p.out, p.k0, p.v0 = a.q.data_ptr(), a.out.data_ptr(), a.k0.data_ptr(), a.v0.data_ptr()
-        p.nq, p.n0 = a.q.shape[0], a.k0.shape[0]
-        p.nq0 = p.nq
-        p.ldq, p.ldo, p.ldkv = a.q.stride(0), a.out.stride(0), a.k0.stride(0)
-        if a.v0.stride(0) != p.ldkv or a.v0.shape[0] != p.n0 or a.out.shape[0] != p.nq or a.q1 is not None:
-            raise ValueError(f"concept_attention[{i}]: k0/v0/out row mismatch, or a second query segment")
-        if a.k1 is not None and a.k1.shape[0] > 0:
-            _chk(a.k1, torch.bfloat16, "k1"), _chk(a.v1, torch.bfloat16, "v1")
-            if a.k1.stride(0) != p.ldkv or a.v1.stride(0) != p.ldkv or a.v1.shape[0] != a.k1.shape[0]:
-                raise ValueError(f"concept_attention[{i}]: both key/value segments must share one row stride")
-            p.k1, p.v1, p.n1 = a.k1.data_ptr(), a.v1.data_ptr(), a.k1.shape[0]
-        if a.out_f32 is not None:
-            _chk(a.out_f32, torch.float32, "out_f32")
-            if a.out_f32.shape[0] != p.nq:
-                raise ValueError(f"concept_attention[{i}]: out_f32 row mismatch")
-            p.out_f32, p.ldo32 = a.out_f32.data_ptr(), a.out_f32.stride(0)
-    _chk(workspace, torch.float32, "workspace")
-    if not workspace.is_contiguous():
-        raise ValueError("concept_attention: workspace must be contiguous")
-    L.check(lib.ca_concept_attn_fwd(arr, len(problems), num_heads, int(bool(qk_f16)), workspace.data_ptr(),
-                                    workspace.numel(), _stream()), "ca_concept_attn_fwd")
-
-
 def attention_stats(reset: bool = False) -> dict:
     """Counters of ca_attn4_kernel's rare softmax paths on the current device (blocking copy; diagnostics only)."""
     import ctypes

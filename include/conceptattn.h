@@ -194,15 +194,6 @@ int ca_attn_fwd_bf16(const ca_attn_problem *problems, int32_t n_problems, int32_
  * for the layers whose heat maps are requested: the bf16 rounding of the rotated q and k is what bounds the output-
  * space maps (modified_double_stream_block.py:185-191 on :112-116), and an 11-bit mantissa costs the MFMA nothing. */
 int ca_attn_fwd_qk16(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads, ca_stream_t stream);
-/* (round 5) The same attention for problems of at most 8 query rows in ONE segment (the C concept rows of a work item,
- * modified_double_stream_block.py:162-168) as a bandwidth problem: the keys split over workgroups (512 each), fp32 dot
- * products and probabilities, the per-chunk softmax states merged by a second small launch.  q carries softmax_scale *
- * log2(e); qk_f16 = 1: q / k hold IEEE half.  Fields used: q, out, out_f32 / ldo32, k0 / v0 / n0, k1 / v1 / n1, nq (1..8),
- * ldq / ldo / ldkv; nq0 = 0 or nq.  `workspace`: fp32 scratch of at least n_problems * num_heads * ceil(max keys / 512)
- * * 8 * 136 floats, caller-owned (the library allocates nothing), 16-byte aligned.  Used in the layers whose heat maps
- * are requested, where the concept rows must be complete before the main launch (ca_attn_problem.hm_con). */
-int ca_concept_attn_fwd(const ca_attn_problem *problems, int32_t n_problems, int32_t num_heads, int32_t qk_f16,
-                        float *workspace, int64_t workspace_floats, ca_stream_t stream);
 /* Diagnostics of the pre-scaled-q kernel's two rare paths on the current device, since the last reset:
  * counters[0] = workgroups whose rows were recomputed with a running maximum (a row sum passed 2^100 or
  * overflowed: a score > 100 octaves above its row's first-tile maximum with no check in between, or inf / NaN inputs),

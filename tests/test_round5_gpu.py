@@ -239,7 +239,6 @@ def test_model_epilogue_logits_equal_the_fp32_row_route():
     B, C, Lp = 3, 3, 256
     m, p, kw = _tiny_forward_kwargs(B)
     kw = dict(kw, stop_after_multimodal_attentions=False)
-    m.concept_kernel = False   # (the concept rows on the MFMA units on both sides: the comparison is about the logits)
     res = {}
     for on in (True, False):
         m.epilogue_logits = on
@@ -252,55 +251,4 @@ def test_model_epilogue_logits_equal_the_fp32_row_route():
     assert torch.equal(res[True][0][:, 1], res[False][0][:, 1])
     d = (res[True][0][:, 0] - res[False][0][:, 0]).abs().max().item()
     assert 0 <= d < 2e-6, d
-    # ... and the concept rows on ca_concept_attn_fwd (fp32 probabilities) instead of the MFMA units (bf16): the image
-    # stream does not see the concept rows at all; the maps move by the MFMA units' rounding of those rows
-    m.epilogue_logits, m.concept_kernel = True, True
-    acc = torch.zeros(B, 2, C, Lp, device=DEV)
-    pred, _ = m(heatmaps=[HeatmapRequest(tuple(range(p.depth)), 0.5, acc[j, 0], acc[j, 1]) for j in range(B)], **kw)
-    assert torch.equal(pred, res[True][1])
-    dk = (acc - res[True][0]).abs().max().item()
-    assert 0 < dk < 2e-3, dk
-
-
-@pytest.mark.parametrize("qk_f16", [False, True])
-@pytest.mark.parametrize("C,n0,n1,NH", [(4, 4, 4096, 24), (1, 1, 100, 2), (8, 8, 1000, 3), (3, 3, 0, 2), (4, 700, 0, 2),
-                                        (5, 5, 513, 1)])
-def test_concept_attention_kernel_vs_fp32(C, n0, n1, NH, qk_f16):
-    """ca_concept_attn_fwd (<= 8 query rows, keys split over workgroups, fp32 scores and probabilities, two key / value
-    segments, ragged last chunk, one chunk only) against an fp32 attention of the same bf16 / half inputs: 2e-5 on the
-    fp32 rows (summation order only), the bf16 rows their rounding; several problems per launch; and against the MFMA
-    kernel's concept units (which round the probabilities to bf16)."""
-    H = NH * 128
-    g = torch.Generator(device="cpu").manual_seed(C * 1000 + n1)
-    nk = n0 + n1
-    q = (torch.randn(C, H, generator=g) * 0.35).to(DEV)
-    k = torch.randn(nk, H, generator=g).to(DEV)
-    v = torch.randn(nk, H, generator=g).to(DEV)
-    cast = (lambda t: t.half().view(torch.bfloat16)) if qk_f16 else (lambda t: t.bfloat16())
-    back = (lambda t: t.view(torch.float16).float()) if qk_f16 else (lambda t: t.float())
-    qb, kb, vb = cast(q), cast(k), v.bfloat16()
-    ws = torch.zeros(ops.concept_attention_workspace_floats(2, NH, nk), device=DEV)
-    out = [torch.zeros(C, H, device=DEV, dtype=torch.bfloat16) for _ in range(2)]
-    o32 = [torch.zeros(C, H, device=DEV) for _ in range(2)]
-    probs = [ops.Attn(qb, out[0], kb[:n0], vb[:n0], kb[n0:] if n1 else None, vb[n0:] if n1 else None, out_f32=o32[0]),
-             ops.Attn(qb, out[1], kb, vb, out_f32=o32[1])]          # the same keys as ONE segment
-    ops.concept_attention(probs, NH, ws, qk_f16=qk_f16)
-    torch.cuda.synchronize()
-    qf, kf, vf = back(qb).view(C, NH, 128), back(kb).view(nk, NH, 128), vb.float().view(nk, NH, 128)
-    s = torch.einsum("qhd,khd->hqk", qf.double(), kf.double())
-    pr = torch.exp2(s - s.max(-1, keepdim=True).values)
-    ref = torch.einsum("hqk,khd->qhd", pr / pr.sum(-1, keepdim=True), vf.double()).reshape(C, H).float()
-    assert torch.equal(o32[0], o32[1]) and torch.equal(out[0], out[1])      # the segment split changes no bit
-    assert (o32[0] - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
-    assert torch.equal(out[0], o32[0].bfloat16())
-    mf = torch.zeros(C, H, device=DEV, dtype=torch.bfloat16)
-    mf32 = torch.zeros(C, H, device=DEV)
-    ops.attention([ops.Attn(qb, mf, kb[:n0], vb[:n0], kb[n0:] if n1 else None, vb[n0:] if n1 else None, out_f32=mf32)],
-                  NH, q_prescaled=True, qk_f16=qk_f16)
-    assert (mf32 - ref).abs().max().item() < 8e-3 * max(1.0, ref.abs().max().item())    # (bf16 probabilities)
-    assert (o32[0] - ref).abs().max().item() <= (mf32 - ref).abs().max().item() + 1e-6
-    with pytest.raises(ValueError):
-        ops.concept_attention(probs, NH, ws[:100], qk_f16=qk_f16)      # workspace too small
-    with pytest.raises(ValueError):
-        big = torch.zeros(9, H, device=DEV, dtype=torch.bfloat16)
-        ops.concept_attention([ops.Attn(big, big.clone(), kb, vb)], NH, ws, qk_f16=qk_f16)   # more than 8 rows
+    m.epilogue_logits = True
