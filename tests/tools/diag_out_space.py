@@ -58,6 +58,7 @@ def main():
     pl = ConceptAttentionFluxPipeline("flux-schnell", device=DEV, weights=None)
     pl.model.weights.init_synthetic(seed=0, on_device=False)
     m, p = pl.model, pl.params
+    m.epilogue_logits = False   # (round 5: this stage-by-stage diagnosis reads the fp32 rows of the attention output)
     inp = {k: (v.bfloat16().float() if v.is_floating_point() else v)
            for k, v in synthetic_inputs(p, 1024, 1024, 256, 4, seed=5).items()}
     d = {k: v.to(DEV) for k, v in inp.items()}
