@@ -1326,6 +1326,10 @@ int launch_thin_mf(const GemmLaunch &L, int groups, hipStream_t stream) {
 }
 
 int launch_thin(const GemmLaunch &L, hipStream_t stream) {
+  // (diagnostic builds, TIMING ONLY: CA_GEMM_KO_THIN=1 skips every thin-row launch -- wrong results; the ceiling of
+  // anything that could still be done about those rows, tools/env_ab.py)
+  static const int ko = ca_ab_env("CA_GEMM_KO_THIN", 0);
+  if (ko) return CA_OK;
   int rows = 1;  // rows of the longest thin part
   bool heads = false;   // the fused QK-norm + RoPE epilogue needs a head's 128 columns in one workgroup
   for (int i = 0; i < CA_GEMM_MAX_PROBLEMS; ++i)
